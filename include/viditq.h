@@ -1,0 +1,182 @@
+/*
+ * viditq.h - C ABI of libviditq_hip.so: the MI355X (gfx950) kernels of the
+ * quantized-DiT denoising path.
+ *
+ * The reference (thu-nics/ViDiT-Q) has no FFI layer: its operator API is the
+ * Python class surface of qdiff.  Each entry point below
+ * replaces the torch ops executed by the cited reference lines; the Python
+ * host package (vidit-q_amd) binds them with ctypes and keeps the reference's
+ * class/method names on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; no hidden
+ *     allocation, no host synchronisation; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream);
+ *   - return value: VQ_OK (0) or a negative VQ_E* code; nothing throws;
+ *   - activations are fp16 (`uint16_t` bit patterns, IEEE binary16), row-major,
+ *     rows contiguous; quantized activations are int8 `code - cx` with row
+ *     stride `Kp` (a multiple of 128 bytes, the tail beyond K is zero);
+ *   - "row" r of an activation [B, n_tok, C] is r = b*n_tok + tok; per-token
+ *     quant parameters are shared over b (reference quirk) and
+ *     are stored replicated per row so the GEMM never needs n_tok.
+ *
+ * Integer form computed by the GEMMs:
+ *   out[m,n] = sx[m]*sw[n] * ( acc[m,n] - zw[n]*R[m] - zx[m]*cs[n] ) + bias[n]
+ *   acc = sum_k xs[m,k]*ws[n,k];  xs = code_x - cx, ws = code_w - cw
+ *   zx = zp_x - cx, zw = zp_w - cw, cs[n] = sum_k ws[n,k],
+ *   R[m] = sum_k xs[m,k] - K*zx[m]
+ */
+#ifndef VIDITQ_H
+#define VIDITQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQ_OK 0
+#define VQ_EINVAL (-1)   /* bad argument (null pointer, non-positive size) */
+#define VQ_ESHAPE (-2)   /* unsupported shape / alignment */
+#define VQ_ELAUNCH (-3)  /* hip launch error (see vq_last_hip_error) */
+#define VQ_EUNSUP (-4)   /* unsupported bit-width / mode */
+
+/* status-word bits written by the quantizing kernels (device int32) */
+#define VQ_ST_EPSFILL 1  /* some token had delta < 1e-6: the reference would fill
+                            EVERY delta with 1e-6 (base_quantizer.py:220-222) */
+
+/* GEMM epilogues */
+#define VQ_EPI_NONE 0        /* out = y                                        */
+#define VQ_EPI_GELU 1        /* out = gelu_tanh(y)      (mlp.fc1 -> act)       */
+#define VQ_EPI_GATE_RESID 2  /* out = resid + gate[b,n]*y   (x = x + gate*f(x)) */
+#define VQ_EPI_RESID 3       /* out = resid + y             (x = x + cross(x)) */
+
+int vq_version(void);
+const char* vq_strerror(int code);
+int vq_last_hip_error(void);
+
+/* ---- per-token dynamic activation quantizer ------------------------------
+ * Replaces DynamicActQuantizer.forward (qdiff/quantizer/dynamic_quantizer.py:
+ * 16-45) + init_quant_params token branch (base_quantizer.py:177-228) as used
+ * by every QuantLayer subclass (quant_layer.py:157-165, stdit_quant_layer.py:
+ * 68-73,159-164,270-281), optionally preceded by the smooth-quant division
+ * x / s (quant_layer.py:140) and the temporal pos-embed add (stdit.py:113-114).
+ *
+ * x        [B*n_tok, C] fp16
+ * add_rows nullable [n_add, C] fp16 added to row r as add_rows[(r % n_tok) / add_div]
+ * s        nullable [C] fp32 smooth-quant channel scale; x is DIVIDED by s in-kernel
+ *          (correctly rounded division, bit-exact with the reference's x / s)
+ * xq       [B*n_tok, Kp] int8 (code - cx, cx = 128 when n_bits==8 else 0)
+ * sx       [B*n_tok] fp32 delta      zx [B*n_tok] int32 (zp - cx)
+ * R        [B*n_tok] int32           zpf nullable [B*n_tok] fp32 (raw zero point)
+ * status   nullable device int32 (bit VQ_ST_EPSFILL or-ed in)
+ */
+int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, const float* s,
+                int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf,
+                int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
+
+/* Same, fused with LayerNorm(eps, no affine) + AdaLN modulate:
+ *   x_m = LN(x) * (1 + scale[b]) + shift[b]       (stdit.py:100-103,124)
+ * shift/scale: fp32 [B, C] (already scale_shift_table + t0 chunk).
+ * Up to three smoothing vectors s0..s2 produce up to three quantized copies
+ * (q/k/v each balance against their own weight, quant_layer.py:136); n_out>=1.
+ * xm_out nullable [B*n_tok, C] fp16: the modulated activation itself.
+ */
+int vq_ln_modulate_rowquant(const void* x, const float* shift, const float* scale, float ln_eps,
+                            int n_out, const float* const* s, int8_t* const* xq, float* const* sx,
+                            int32_t* const* zx, int32_t* const* R, void* xm_out,
+                            int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
+
+/* Quantize->dequantize (the reference's fake-quant result), exact incl. the
+ * global eps-fill rule; the operator behind BaseQuantizer.forward for
+ * activations (base_quantizer.py:112-144, dynamic_quantizer.py:16-45).
+ * mode 0: per-token dynamic (delta/zp computed, written to delta_out/zp_out [n_tok])
+ * mode 1: static (delta_in/zp_in given: 1 element tensor-wise or n_tok per-token)
+ * codes nullable [B*n_tok, C] uint8 raw codes.  `scratch` = 1 device float (mode 0).
+ */
+int vq_fakequant_act(const void* x, void* out, uint8_t* codes, float* delta_out, float* zp_out,
+                     const float* delta_in, const float* zp_in, int n_param,
+                     int B, int n_tok, int C, int n_bits, int mode, float* scratch,
+                     int32_t* status, void* stream);
+
+/* ---- weight packer ---------------------------------------------------------
+ * Replaces WeightQuantizer.forward on W*s (base_quantizer.py:129-144 via
+ * quant_layer.py:174-185): codes = clamp(round(W*s/delta)+zp, 0, 2^b-1) on the
+ * grid (delta, zp) given per out-channel; emits ws = code - cw as int8 [N, Kp]
+ * (n_bits > 4) or packed nibbles [N, Kp/2] (n_bits <= 4; per group of 8 k, byte j
+ * holds code[k0+j] in the low and code[k0+4+j] in the high nibble - pack.hip),
+ * zw[n] = zp - cw, sw[n] = delta, cs[n] = sum_k ws.  cw = 128 iff n_bits == 8.
+ * W [N,K] fp16; s nullable [K] fp32; delta, zp [N] fp32.
+ */
+int vq_pack_weight(const void* W, const float* s, const float* delta, const float* zp,
+                   void* wq, float* sw, int32_t* zw, int32_t* cs,
+                   int N, int K, int Kp, int n_bits, void* stream);
+
+/* Per-out-channel min-max grid of W*s (base_quantizer.py:168-172,191-228):
+ * delta[n], zp[n] for one bit-width; status gets VQ_ST_EPSFILL like above and
+ * a second call with force_eps=1 reproduces the fill. */
+int vq_weight_minmax(const void* W, const float* s, float* delta, float* zp,
+                     int N, int K, int n_bits, int force_eps, int32_t* status, void* stream);
+
+/* ---- int8 MFMA GEMM with fused dequant epilogue ----------------------------
+ * Replaces F.linear(x_hat, W_hat, bias) of quant_layer.py:211 /
+ * stdit_quant_layer.py:96,187,304 / dit_quant_layer.py:29,76 (and, by
+ * epilogue, nn.GELU(tanh) of modules.py:57 and the gate/residual adds of
+ * stdit.py:109,118,121,128).
+ * xq [M,Kp] int8, wq [N,Kp] int8 (w_bits>4) or [N,Kp/2] nibbles (w_bits<=4)
+ * bias nullable [N] fp32; out [M, ldo] fp16 written at columns [0,N)
+ * resid nullable [M, ldo] fp16; gate nullable fp32 [M/rows_per_gate, N]
+ */
+int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R,
+               const void* wq, const float* sw, const int32_t* zw, const int32_t* cs,
+               const float* bias, void* out, int ldo, const void* resid, const float* gate,
+               int rows_per_gate, int M, int N, int K, int Kp, int w_bits, int epilogue,
+               int variant, void* stream);
+
+/* ---- fp16 attention (fp32 online softmax) -----------------------------------
+ * Replaces flash_attn_func / the softmax branch of Attention.forward
+ * (opensora/models/layers/blocks.py:169-187), xformers block-diagonal
+ * memory_efficient_attention (blocks.py:302-304) and PixArt self-attention
+ * (t2i/diffusion/model/nets/PixArt_blocks.py:151-155).
+ * Element (sequence i, token t, head h, dim d) of q is at
+ *   q + i*q_seq_stride + t*q_tok_stride + h*D + d      (strides in elements,
+ * multiples of 8); k, v use kv_*_stride, o uses o_*_stride.  With kv_off
+ * (device int32 [n_seq+1], nullable) sequence i attends to kv rows
+ * [kv_off[i], kv_off[i+1]) at kv_tok_stride (block-diagonal / varlen cross
+ * attention) and kv_seq_stride / Lk are ignored.  D in {16, 32, 64, 72}.
+ */
+int vq_attn_fwd(const void* q, const void* k, const void* v, void* o,
+                int n_seq, int Lq, int Lk, int H, int D,
+                long q_seq_stride, long q_tok_stride, long kv_seq_stride, long kv_tok_stride,
+                long o_seq_stride, long o_tok_stride, const int32_t* kv_off,
+                float scale, void* stream);
+
+/* Temporal attention of STDiTBlock (stdit.py:112-118): rows are laid out
+ * [B][T][S] (row = (b*T + t)*S + s, row strides ld_in / ld_out elements) and
+ * attention runs over t for every (b, s, head).  T <= 16. */
+int vq_attn_temporal(const void* q, const void* k, const void* v, void* o,
+                     int B, int T, int S, int H, int D, long ld_in, long ld_out,
+                     float scale, void* stream);
+
+/* ---- small fused elementwise helpers ---------------------------------------
+ * mod[b, j, c] = table[j, c] + t0[b, j*C + c]  (stdit.py:100-102), fp32 out. */
+int vq_adaln_table(const void* table, const void* t0, float* mod, int B, int J, int C, void* stream);
+
+/* Fused CFG + DDIM(eta=0) update of the kept half of the batch: replaces the tail of
+ * forward_with_cfg (t2v/opensora/schedulers/iddpm/__init__.py:168-184; PTQD division by
+ * 1+k, guidance on eps[:, :3] only) and p_mean_variance + ddim_sample
+ * (iddpm/gaussian_diffusion.py:252-335,514-552).  cond/uncond fp32 [n,2C,inner] model
+ * outputs, x / x_out fp32 [n,C,inner]; A = sqrt_recip_alphas_cumprod[t],
+ * Bc = sqrt_recipm1_alphas_cumprod[t], abar_prev = alphas_cumprod_prev[t]. */
+int vq_cfg_ddim_step(const float* cond, const float* uncond, const float* x, float* x_out,
+                     int n, int C, int inner, float cfg, float one_plus_k,
+                     float A, float Bc, float abar_prev, void* stream);
+
+/* MFMA lane-layout probe (test infrastructure of the library itself): fills
+ * out[32*32] int32 with A(32x32,i8) * B^T using one wave; a,b are [32,32] int8. */
+int vq_probe_mfma_i8(const int8_t* a, const int8_t* b, int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDITQ_H */

@@ -1,0 +1,314 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against the CPU oracle.
+
+Integer codes / per-row integer terms are compared bit-exactly; floating outputs within the
+tolerance written next to each assert (fp16 output rounding is 2^-11 relative).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fakequant as fq
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def h16(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+# ----------------------------------------------------------------------------- MFMA layout
+def test_mfma_i8_layout_probe(ops, dev):
+    g = torch.Generator().manual_seed(1)
+    a = torch.randint(-128, 128, (32, 32), generator=g, dtype=torch.int8)
+    b = torch.randint(-128, 128, (32, 32), generator=g, dtype=torch.int8)  # asymmetric on purpose
+    out = ops.probe_mfma_i8(a.to(dev), b.to(dev)).cpu()
+    ref = a.int() @ b.int().t()
+    assert torch.equal(out, ref)
+
+
+# ----------------------------------------------------------------------------- rowquant
+@pytest.mark.parametrize("B,n_tok,C", [(1, 64, 64), (2, 37, 96), (1, 128, 1152), (2, 16, 4608), (1, 5, 8)])
+@pytest.mark.parametrize("n_bits", [8, 6])
+def test_rowquant_bit_exact(ops, dev, B, n_tok, C, n_bits):
+    x = h16(B, n_tok, C, scale=3.0, seed=B * 1000 + C)
+    x[0, 0, :] = x[0, 0, :].abs()        # all-positive token (min clamps to 0)
+    if n_tok > 1:
+        x[-1, 1, :] = -x[-1, 1, :].abs()  # all-negative token
+    codes, dq, delta, zp, eps = fq.dyn_act_quant(x.float(), n_bits)
+    assert not eps
+    st = ops.new_status(dev)
+    qa = ops.rowquant(x.to(dev), n_bits=n_bits, status=st, want_zp=True)
+    cx = 128 if n_bits == 8 else 0
+    got_codes = qa.xq[:, :C].cpu().int() + cx
+    assert torch.equal(got_codes.reshape(B, n_tok, C), codes.int())
+    assert torch.all(qa.xq[:, C:] == 0)
+    assert torch.equal(qa.sx.cpu().reshape(B, n_tok), delta.reshape(1, n_tok).expand(B, n_tok))
+    assert torch.equal(qa.zpf.cpu().reshape(B, n_tok), zp.reshape(1, n_tok).expand(B, n_tok))
+    zx = (zp.reshape(1, n_tok).expand(B, n_tok).int() - cx)
+    assert torch.equal(qa.zx.cpu().reshape(B, n_tok), zx)
+    R = (codes.int() - cx).sum(-1) - C * zx
+    assert torch.equal(qa.R.cpu().reshape(B, n_tok), R)
+    assert int(st.item()) == 0
+
+
+def test_rowquant_smooth_and_add(ops, dev):
+    B, T, S, C = 2, 4, 8, 96
+    x = h16(B, T * S, C, scale=2.0, seed=3)
+    tpe = h16(T, C, scale=0.5, seed=4)
+    s = (torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5).float()
+    xin = (x.float().reshape(B, T, S, C) + tpe.float().reshape(1, T, 1, C)).reshape(B, T * S, C) / s
+    codes, dq, delta, zp, _ = fq.dyn_act_quant(xin, 8)
+    qa = ops.rowquant(x.to(dev), s=s.to(dev), add_rows=tpe.to(dev), add_div=S, want_zp=True)
+    assert torch.equal(qa.xq[:, :C].cpu().int().reshape(B, T * S, C) + 128, codes.int())
+    assert torch.equal(qa.sx.cpu().reshape(B, -1)[0], delta.reshape(-1))
+
+
+def test_rowquant_flags_eps_row(ops, dev):
+    x = h16(1, 8, 64, seed=7)
+    x[0, 3, :] = 0  # constant token: delta = 0 < 1e-6 -> reference fills EVERY delta with eps
+    st = ops.new_status(dev)
+    ops.rowquant(x.to(dev), status=st)
+    assert int(st.item()) & 1
+
+
+def test_fakequant_act_exact_including_eps_fill(ops, dev):
+    for degenerate in (False, True):
+        x = h16(2, 24, 64, scale=2.0, seed=11)
+        if degenerate:
+            x[:, 5, :] = 0
+        codes, dq, delta, zp, eps = fq.dyn_act_quant(x.float(), 8)
+        assert eps == degenerate
+        st = ops.new_status(dev)
+        out, got_codes, d, z = ops.fakequant_act(x.to(dev), 8, status=st, want_codes=True)
+        assert torch.equal(d.cpu(), delta.reshape(-1))
+        assert torch.equal(z.cpu(), zp.reshape(-1))
+        assert torch.equal(got_codes.cpu().int(), codes.int())
+        assert torch.equal(out.cpu(), dq.half())   # dequant exact up to the final fp16 rounding
+        assert (int(st.item()) & 1) == int(degenerate)
+    # static tensor-wise
+    x = h16(2, 24, 64, scale=2.0, seed=12)
+    d, z = fq.tensor_params(x.float(), 8)
+    codes, dq = fq.static_act_quant(x.float(), d, z, 8)
+    out, got_codes, _, _ = ops.fakequant_act(x.to(dev), 8, delta=d.reshape(1).to(dev), zp=z.reshape(1).to(dev),
+                                             want_codes=True)
+    assert torch.equal(got_codes.cpu().int(), codes.int())
+    assert torch.equal(out.cpu(), dq.half())
+
+
+# ----------------------------------------------------------------------------- weights
+@pytest.mark.parametrize("n_bits", [8, 6, 4])
+@pytest.mark.parametrize("smooth", [False, True])
+def test_weight_minmax_and_pack(ops, dev, n_bits, smooth):
+    N, K = 48, 96
+    W = h16(N, K, scale=0.05, seed=21)
+    s = (torch.rand(K, generator=torch.Generator().manual_seed(2)) + 0.5).float() if smooth else None
+    Weff = W.float() * s if smooth else W.float()
+    delta, zp = fq.weight_params(Weff, n_bits)
+    codes, _ = fq.weight_fakequant(Weff, delta, zp, n_bits)
+    d, z = ops.weight_minmax(W.to(dev), n_bits, s=None if s is None else s.to(dev))
+    assert torch.equal(d.cpu(), delta.reshape(-1))
+    assert torch.equal(z.cpu(), zp.reshape(-1))
+    pw = ops.pack_weight(W.to(dev), d, z, n_bits, s=None if s is None else s.to(dev))
+    cw = 128 if n_bits == 8 else 0
+    if n_bits <= 4:
+        raw = pw.wq.cpu()                                   # [N, Kp/2]
+        w32 = raw.reshape(N, -1, 4).int()                   # bytes of each uint32 group
+        lo = (w32 & 0xF)                                    # k0+j
+        hi = (w32 >> 4) & 0xF                               # k0+4+j
+        got = torch.cat([lo, hi], dim=-1).reshape(N, -1)[:, :K]
+    else:
+        got = pw.wq.cpu().int()[:, :K] + cw
+        assert torch.all(pw.wq[:, K:] == 0)
+    assert torch.equal(got, codes.int())
+    assert torch.equal(pw.zw.cpu(), zp.reshape(-1).int() - cw)
+    assert torch.equal(pw.cs.cpu(), (codes.int() - cw).sum(-1))
+
+
+# ----------------------------------------------------------------------------- GEMM
+def _oracle_linear(x, W, b, w_bits, a_bits, s=None):
+    return fq.quant_linear(x.float(), W.float(), None if b is None else b.float(), w_bits=w_bits, a_bits=a_bits,
+                           smooth=None if s is None else s.reshape(1, -1))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(64, 48, 96), (300, 292, 128), (512, 576, 1152), (130, 1152, 4608)])
+def test_gemm_w8a8_vs_oracle(ops, dev, variant, M, N, K):
+    x = h16(1, M, K, scale=1.5, seed=M + K)
+    W = h16(N, K, scale=0.04, seed=N)
+    b = h16(N, scale=0.1, seed=5).float()
+    ref = _oracle_linear(x, W, b, 8, 8)[0]
+    qa = ops.rowquant(x.to(dev))
+    d, z = ops.weight_minmax(W.to(dev), 8)
+    pw = ops.pack_weight(W.to(dev), d, z, 8)
+    out = ops.gemm_i8(qa, pw, bias=b.to(dev), variant=variant).cpu().float()
+    # fp16 output rounding only: 2^-11 relative per element
+    assert rel_l2(out, ref) < 5e-4
+    assert (out - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("w_bits", [4, 6])
+def test_gemm_low_bit_weights(ops, dev, w_bits):
+    M, N, K = 200, 96, 256
+    x = h16(2, M // 2, K, scale=1.5, seed=1)
+    W = h16(N, K, scale=0.04, seed=2)
+    s = (torch.rand(K, generator=torch.Generator().manual_seed(3)) + 0.5).float()
+    ref = _oracle_linear(x, W, None, w_bits, 8, s=s).reshape(M, N)
+    qa = ops.rowquant(x.to(dev), s=s.to(dev))
+    d, z = ops.weight_minmax(W.to(dev), w_bits, s=s.to(dev))
+    pw = ops.pack_weight(W.to(dev), d, z, w_bits, s=s.to(dev))
+    out = ops.gemm_i8(qa, pw).cpu().float()
+    assert rel_l2(out, ref) < 5e-4
+
+
+def test_gemm_epilogues(ops, dev):
+    B, n_tok, N, K = 2, 80, 96, 128
+    M = B * n_tok
+    x = h16(B, n_tok, K, scale=1.5, seed=1)
+    W = h16(N, K, scale=0.04, seed=2)
+    b = h16(N, scale=0.1, seed=3).float()
+    resid = h16(M, N, scale=1.0, seed=4)
+    gate = h16(B, N, scale=0.5, seed=5).float()
+    y = _oracle_linear(x, W, b, 8, 8).reshape(M, N)
+    qa = ops.rowquant(x.to(dev))
+    d, z = ops.weight_minmax(W.to(dev), 8)
+    pw = ops.pack_weight(W.to(dev), d, z, 8)
+    out = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=ops.EPI_GELU).cpu().float()
+    assert rel_l2(out, fq.gelu_tanh(y)) < 5e-4
+    out = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=ops.EPI_RESID, resid=resid.to(dev)).cpu().float()
+    assert rel_l2(out, resid.float() + y) < 5e-4
+    g_full = gate.reshape(B, 1, N).expand(B, n_tok, N).reshape(M, N)
+    out = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=ops.EPI_GATE_RESID, resid=resid.to(dev), gate=gate.to(dev),
+                      rows_per_gate=n_tok).cpu().float()
+    assert rel_l2(out, resid.float() + g_full * y) < 5e-4
+    # in-place residual update (out aliases resid) is how the block pipeline uses it
+    r2 = resid.to(dev).clone()
+    ops.gemm_i8(qa, pw, bias=b.to(dev), out=r2, epilogue=ops.EPI_RESID, resid=r2)
+    assert rel_l2(r2.cpu().float(), resid.float() + y) < 5e-4
+
+
+def test_gemm_full_tile_property_linearity(ops, dev):
+    """Full-size tile grid (M=16384): integer form must be exactly linear in the codes:
+    doubling sx doubles (out - bias); checked against a torch fp32 matmul of the dequantized operands."""
+    M, N, K = 16384, 1152, 1152
+    x = h16(1, M, K, scale=1.0, seed=9).to(dev)
+    W = h16(N, K, scale=0.03, seed=10).to(dev)
+    qa = ops.rowquant(x, want_zp=True)
+    d, z = ops.weight_minmax(W, 8)
+    pw = ops.pack_weight(W, d, z, 8)
+    out = ops.gemm_i8(qa, pw).float()
+    xh = (qa.xq[:, :K].float() + 128 - qa.zpf[:, None]) * qa.sx[:, None]
+    wh = (pw.wq[:, :K].float() + 128 - z[:, None]) * d[:, None]
+    ref = xh @ wh.t()
+    assert rel_l2(out, ref) < 5e-4
+    qa2 = ops.QAct(qa.xq, qa.sx * 2, qa.zx, qa.R, qa.K)
+    out2 = ops.gemm_i8(qa2, pw).float()
+    assert rel_l2(out2, 2 * ref) < 5e-4
+
+
+# ----------------------------------------------------------------------------- LN + modulate + quant
+@pytest.mark.parametrize("B,n_tok,C,nout", [(1, 64, 64, 1), (2, 32, 1152, 3)])
+def test_ln_modulate_rowquant(ops, dev, B, n_tok, C, nout):
+    x = h16(B, n_tok, C, scale=2.0, seed=31)
+    shift = h16(B, C, scale=0.3, seed=32).float()
+    scale = h16(B, C, scale=0.3, seed=33).float()
+    smooth = [None] + [(torch.rand(C, generator=torch.Generator().manual_seed(40 + j)) + 0.5).float()
+                       for j in range(nout - 1)]
+    xm = fq.t2i_modulate(fq.layernorm_noaffine(x.float()), shift[:, None, :], scale[:, None, :])
+    outs, xm_got = ops.ln_modulate_rowquant(x.to(dev), shift.to(dev), scale.to(dev), 1e-6,
+                                            smooth=[None if s is None else s.to(dev) for s in smooth], want_xm=True)
+    assert rel_l2(xm_got.cpu().float(), xm) < 5e-4
+    for s, qa in zip(smooth, outs):
+        xin = xm if s is None else xm / s
+        codes, dq, delta, zp, _ = fq.dyn_act_quant(xin, 8)
+        got = qa.xq[:, :C].cpu().int().reshape(B, n_tok, C) + 128
+        # LN statistics differ in the last ulp from torch's kernel, so a code may flip by one at a
+        # rounding boundary: require <=1 code difference and <0.5% flips, and tight dequant parity.
+        diff = (got - codes.int()).abs()
+        assert int(diff.max()) <= 1
+        assert float((diff > 0).float().mean()) < 5e-3
+        got_dq = (got.float() - (qa.zx.cpu().reshape(B, n_tok, 1) + 128)) * qa.sx.cpu().reshape(B, n_tok, 1)
+        assert rel_l2(got_dq, dq) < 2e-3
+        assert torch.allclose(qa.sx.cpu().reshape(B, n_tok)[0], delta.reshape(-1), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale):
+    # q [n,Lq,H,D] k,v [n,Lk,H,D] ; fp32 softmax  (blocks.py:179-187)
+    a = torch.einsum("nqhd,nkhd->nhqk", q.float() * scale, k.float()).softmax(-1)
+    return torch.einsum("nhqk,nkhd->nqhd", a, v.float())
+
+
+@pytest.mark.parametrize("n_seq,L,H,D", [(2, 1024, 2, 72), (3, 100, 4, 16), (1, 256, 2, 64), (2, 65, 3, 32)])
+def test_attn_fwd_self(ops, dev, n_seq, L, H, D):
+    Cc = H * D
+    qkv = h16(n_seq * L, 3 * Cc, scale=1.0, seed=L + D).to(dev)
+    o = torch.empty((n_seq * L, Cc), dtype=torch.float16, device=dev)
+    ld = 3 * Cc
+    ops.attn_fwd(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], o, n_seq, L, L, H, D, L * ld, ld, L * ld, ld, L * Cc, Cc)
+    q, k, v = [t.cpu().reshape(n_seq, L, H, D) for t in qkv.split(Cc, dim=1)]
+    ref = _attn_ref(q, k, v, D ** -0.5).reshape(n_seq * L, Cc)
+    assert rel_l2(o.cpu().float(), ref) < 1e-3
+    assert (o.cpu().float() - ref).abs().max() < 4e-3
+
+
+def test_attn_fwd_cross_varlen(ops, dev):
+    B, Nq, H, D = 3, 200, 4, 72
+    Cc = H * D
+    lens = [17, 120, 64]
+    q = h16(B * Nq, Cc, seed=1).to(dev)
+    kv = h16(sum(lens), 2 * Cc, seed=2).to(dev)
+    off = torch.tensor([0, 17, 137, 201], dtype=torch.int32, device=dev)
+    o = torch.empty_like(q)
+    ops.attn_fwd(q, kv, kv[:, Cc:], o, B, Nq, 0, H, D, Nq * Cc, Cc, 0, 2 * Cc, Nq * Cc, Cc, kv_off=off)
+    outs = []
+    qs = q.cpu().reshape(B, Nq, H, D)
+    s = 0
+    for b, Lb in enumerate(lens):
+        kb = kv[s:s + Lb, :Cc].cpu().reshape(1, Lb, H, D)
+        vb = kv[s:s + Lb, Cc:].cpu().reshape(1, Lb, H, D)
+        outs.append(_attn_ref(qs[b:b + 1], kb, vb, D ** -0.5))
+        s += Lb
+    ref = torch.cat(outs).reshape(B * Nq, Cc)
+    assert rel_l2(o.cpu().float(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("B,T,S,H,D", [(1, 16, 64, 16, 72), (2, 4, 9, 4, 16), (1, 16, 1024, 16, 72)])
+def test_attn_temporal(ops, dev, B, T, S, H, D):
+    Cc = H * D
+    qkv = h16(B * T * S, 3 * Cc, seed=T + S).to(dev)
+    o = torch.empty((B * T * S, Cc), dtype=torch.float16, device=dev)
+    ops.attn_temporal(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], o, B, T, S, H, D, 3 * Cc, Cc)
+    q, k, v = [t.cpu().reshape(B, T, S, H, D).permute(0, 2, 1, 3, 4).reshape(B * S, T, H, D)
+               for t in qkv.split(Cc, dim=1)]
+    ref = _attn_ref(q, k, v, D ** -0.5).reshape(B, S, T, Cc).permute(0, 2, 1, 3).reshape(B * T * S, Cc)
+    assert rel_l2(o.cpu().float(), ref) < 1e-3
+
+
+# ----------------------------------------------------------------------------- small fused helpers
+def test_adaln_table_and_cfg_ddim(ops, dev):
+    B, J, C = 2, 6, 64
+    table, t0 = h16(J, C, seed=1), h16(B, J * C, seed=2)
+    mod = ops.adaln_table(table.to(dev), t0.to(dev)).cpu()
+    assert torch.equal(mod, table.float()[None] + t0.float().reshape(B, J, C))
+
+    n, Cc, inner = 2, 4, 16 * 8 * 8
+    g = torch.Generator().manual_seed(5)
+    cond = torch.randn(n, 2 * Cc, inner, generator=g)
+    unc = torch.randn(n, 2 * Cc, inner, generator=g)
+    x = torch.randn(n, Cc, inner, generator=g)
+    cfg, k, A, Bc, abp = 4.0, 0.0, 1.7, 1.3, 0.4
+    out = ops.cfg_ddim_step(cond.to(dev), unc.to(dev), x.to(dev), cfg, 1 + k, A, Bc, abp).cpu()
+    mo_c, mo_u = cond / (1 + k), unc / (1 + k)
+    eps = torch.cat([mo_u[:, :3] + cfg * (mo_c[:, :3] - mo_u[:, :3]), mo_c[:, 3:4]], dim=1)
+    x0 = torch.tensor(A) * x - torch.tensor(Bc) * eps
+    e2 = (torch.tensor(A) * x - x0) / torch.tensor(Bc)
+    ref = x0 * torch.sqrt(torch.tensor(abp)) + torch.sqrt(torch.tensor(1 - abp)) * e2
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)

@@ -1,0 +1,71 @@
+"""ctypes binding of libviditq_hip.so (C ABI in include/viditq.h).
+
+There is NO fallback: if the library cannot be loaded the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libviditq_hip.so")
+
+VQ_OK = 0
+VQ_ST_EPSFILL = 1
+EPI_NONE, EPI_GELU, EPI_GATE_RESID, EPI_RESID = 0, 1, 2, 3
+
+_vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+# name -> (restype, argtypes); mirrors include/viditq.h one to one
+SIGNATURES = {
+    "vq_version": (_i, []),
+    "vq_strerror": (C.c_char_p, [_i]),
+    "vq_last_hip_error": (_i, []),
+    "vq_rowquant": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vq_ln_modulate_rowquant": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _i, _i, _i, _i, _i, _vp, _vp]),
+    "vq_fakequant_act": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "vq_pack_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vq_weight_minmax": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vq_gemm_i8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp,
+                        _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _vp, _f, _vp]),
+    "vq_attn_temporal": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _f, _vp]),
+    "vq_adaln_table": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vq_probe_mfma_i8": (_i, [_vp, _vp, _vp, _vp]),
+    "vq_cfg_ddim_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
+}
+
+_lib = None
+
+
+class VQError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH):
+    """Load the shared library and bind every symbol include/viditq.h declares."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise VQError(
+            "libviditq_hip.so not found at %s - build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+            "(hipcc --offload-arch=gfx950); there is no CPU/eager fallback for the product path" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = ""):
+    if code != VQ_OK:
+        lib = load()
+        msg = lib.vq_strerror(code).decode()
+        extra = ""
+        if code == -3:
+            extra = " (hipError %d)" % lib.vq_last_hip_error()
+        raise VQError("%s failed: %s%s" % (what or "viditq call", msg, extra))

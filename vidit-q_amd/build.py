@@ -1,0 +1,68 @@
+"""Build libviditq_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libviditq_hip.so")
+SOURCES = ["api.hip", "rowquant.hip", "pack.hip", "gemm_i8.hip", "attention.hip", "sampler.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(os.path.dirname(CSRC), "..", "include", "viditq.h"))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every kernel source to objects (in parallel) and link the shared library."""
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(sp)
+                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, "vq_common.h"))):
+            procs.append((src, obj, None))
+            continue
+        cmd = [hipcc, *FLAGS, "-c", sp, "-o", obj]
+        if verbose:
+            print("[viditq build]", " ".join(cmd), flush=True)
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    objs = []
+    for src, obj, p in procs:
+        if p is not None:
+            out, _ = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode(errors="replace")))
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print("[viditq build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,322 @@
+// gemm_i8.hip - W8A8 / W4A8 Linear for gfx950: int8 MFMA contraction + fused dequant epilogue.
+//
+// Replaces F.linear(x_hat, W_hat, bias) on fake-quantized operands
+// (qdiff/models/quant_layer.py:211; stdit_quant_layer.py:96,187,304; dit_quant_layer.py:29,76)
+// with the equivalent integer form:
+//   out[m,n] = sx[m]*sw[n] * (acc - zw[n]*R[m] - zx[m]*cs[n]) + bias[n],  acc = sum_k xs*ws  (int32)
+// and, by epilogue, GELU-tanh (modules.py:57) and the gate/residual adds (stdit.py:109,118,121,128).
+//
+// Design (MI355X): one 512-thread workgroup (8 wave64) per BM x BN output tile, 1 workgroup / CU.
+//   - tile 256 tokens x 288 channels: 1152 = 4*288, 3456 = 12*288, 4608 = 16*288, so with
+//     M = 16384 every Linear of the STDiT block is an exact multiple of 256 workgroups (no tail wave);
+//     intensity 256*288/(256+288) = 135 MAC/B of L2->LDS traffic.
+//   - operands are both K-contiguous ([M,Kp] and [N,Kp] int8), staged HBM/L2 -> registers -> LDS in
+//     16-byte chunks, double-buffered (loads of tile t+1 fly under the MFMAs of tile t, one barrier/tile),
+//     LDS rows XOR-swizzled at 16-byte granularity so every ds_read_b128 fragment read is conflict-free.
+//   - MFMA v_mfma_i32_32x32x32_i8 with the WEIGHT fragment as the A operand and the TOKEN fragment as
+//     the B operand, i.e. each wave computes D^T[n][m]: a lane then owns ONE token (column) and four
+//     consecutive channels per accumulator quad -> per-token dequant terms are lane constants and the
+//     fp16 result is stored as 8-byte pieces of a row.
+//   - blockIdx -> tile map is XCD-aware (8 XCDs, private L2s): consecutive tiles (n fastest) of one token
+//     panel go to the same XCD so the 295 KB activation panel is fetched into that L2 once.
+//   - W4A8: nibble-packed weights are expanded to int8 while being staged (layout in pack.hip).
+//
+// Roofline: MFMA-bound (int8 dense peak 5.03 POPS); algorithmic bytes M*K + N*K(/2) + 2*M*N (+2*M*N
+// when a residual is read).
+#include "vq_common.h"
+
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+    return BK == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // nn.GELU(approximate='tanh'): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float e = __expf(2.0f * u);
+    const float th = 1.0f - __fdiv_rn(2.0f, e + 1.0f);
+    return 0.5f * x * (1.0f + th);
+}
+
+struct GemmArgs {
+    const int8_t* xq;
+    const float* sx;
+    const int32_t* zx;
+    const int32_t* R;
+    const uint8_t* wq;
+    const float* sw;
+    const int32_t* zw;
+    const int32_t* cs;
+    const float* bias;
+    half_t* out;
+    const half_t* resid;
+    const float* gate;
+    int ldo, rows_per_gate, M, N, K, Kp, epilogue;
+};
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool W4>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_kernel(GemmArgs a) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int CH = BK / 16;                       // 16-byte chunks per LDS row
+    constexpr int XCH = BM * CH, WCH = BN * CH;       // chunks per tile
+    constexpr int XPT = (XCH + NT - 1) / NT, WPT = (WCH + NT - 1) / NT;
+    constexpr int STAGE = (BM + BN) * BK;             // bytes per LDS stage
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    // ---- XCD-aware tile mapping (bijective for any tile count) ----
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    const int T = MT * NTl;
+    const int bid = blockIdx.x;
+    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // ---- staging descriptors (per thread, loop-invariant) ----
+    const int8_t* xsrc[XPT];
+    int xdst[XPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int c = tid + i * NT;
+        const int row = c / CH, kc = c % CH;
+        int gm = m0 + row;
+        gm = gm < a.M ? gm : a.M - 1;
+        xsrc[i] = a.xq + (size_t)gm * a.Kp + kc * 16;
+        xdst[i] = row * BK + ((kc ^ swz<BK>(row)) * 16);
+    }
+    const uint8_t* wsrc[WPT];
+    int wdst[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int c = tid + i * NT;
+        const int row = c / CH, kc = c % CH;
+        int gn = n0 + row;
+        gn = gn < a.N ? gn : a.N - 1;
+        wsrc[i] = W4 ? a.wq + (size_t)gn * (a.Kp / 2) + kc * 8 : a.wq + (size_t)gn * a.Kp + kc * 16;
+        wdst[i] = BM * BK + row * BK + ((kc ^ swz<BK>(row)) * 16);
+    }
+
+    int4v xr[XPT], wr[WPT];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+            if (XCH % NT == 0 || tid + i * NT < XCH) xr[i] = *reinterpret_cast<const int4v*>(xsrc[i] + k0);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (WCH % NT == 0 || tid + i * NT < WCH) {
+                if (W4) {
+                    const uint2 p = *reinterpret_cast<const uint2*>(wsrc[i] + k0 / 2);
+                    int4v v;
+                    v[0] = (int)(p.x & 0x0F0F0F0Fu);
+                    v[1] = (int)((p.x >> 4) & 0x0F0F0F0Fu);
+                    v[2] = (int)(p.y & 0x0F0F0F0Fu);
+                    v[3] = (int)((p.y >> 4) & 0x0F0F0F0Fu);
+                    wr[i] = v;
+                } else {
+                    wr[i] = *reinterpret_cast<const int4v*>(wsrc[i] + k0);
+                }
+            }
+    };
+    auto store_tile = [&](int stage) {
+        uint8_t* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i)
+            if (XCH % NT == 0 || tid + i * NT < XCH) *reinterpret_cast<int4v*>(base + xdst[i]) = xr[i];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (WCH % NT == 0 || tid + i * NT < WCH) *reinterpret_cast<int4v*>(base + wdst[i]) = wr[i];
+    };
+
+    int16v acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0;
+
+    // fragment read offsets (per lane): row = lane&31, 16-byte K chunk = 2*ks + (lane>>5)
+    const int frow = lane & 31, fk = lane >> 5;
+    const int nkt = a.Kp / BK;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const uint8_t* xs = smem + cur * STAGE;
+        const uint8_t* ws = xs + BM * BK;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            const int kc = ks * 2 + fk;
+            int4v xf[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 32 + frow;
+                xf[i] = *reinterpret_cast<const int4v*>(xs + row * BK + ((kc ^ swz<BK>(row)) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WTN + j * 32 + frow;
+                const int4v wf = *reinterpret_cast<const int4v*>(ws + row * BK + ((kc ^ swz<BK>(row)) * 16));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf[i], acc[j][i], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: per-channel parameters through LDS, per-token parameters in registers ----
+    float* l_sw = reinterpret_cast<float*>(smem);
+    int* l_zw = reinterpret_cast<int*>(smem) + BN;
+    int* l_cs = reinterpret_cast<int*>(smem) + 2 * BN;
+    float* l_b = reinterpret_cast<float*>(smem) + 3 * BN;
+    for (int c = tid; c < BN; c += NT) {
+        const int gn = n0 + c;
+        const bool ok = gn < a.N;
+        l_sw[c] = ok ? a.sw[gn] : 0.f;
+        l_zw[c] = ok ? a.zw[gn] : 0;
+        l_cs[c] = ok ? a.cs[gn] : 0;
+        l_b[c] = (ok && a.bias) ? a.bias[gn] : 0.f;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
+        const bool mok = m < a.M;
+        const int mc = mok ? m : a.M - 1;
+        const float sxm = a.sx[mc];
+        const int zxm = a.zx[mc], Rm = a.R[mc];
+        const float* grow = a.gate ? a.gate + (size_t)(mc / a.rows_per_gate) * a.N : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int nl = wn * WTN + j * 32 + 8 * rg + 4 * (lane >> 5);
+                const int n = n0 + nl;
+                const float4v fsw = *reinterpret_cast<const float4v*>(l_sw + nl);
+                const int4v izw = *reinterpret_cast<const int4v*>(l_zw + nl);
+                const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
+                const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
+                if (!mok || n >= a.N) continue;  // N % 4 == 0: a quad is all-in or all-out
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tt = acc[j][i][rg * 4 + e] - __mul24(izw[e], Rm) - __mul24(zxm, ics[e]);
+                    y[e] = (sxm * fsw[e]) * (float)tt + fb[e];
+                }
+                const size_t off = (size_t)m * a.ldo + n;
+                if (a.epilogue == VQ_EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f(y[e]);
+                } else if (a.epilogue == VQ_EPI_GATE_RESID) {
+                    const half4 rr = *reinterpret_cast<const half4*>(a.resid + off);
+                    const float4v g = *reinterpret_cast<const float4v*>(grow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (float)rr[e] + g[e] * y[e];
+                } else if (a.epilogue == VQ_EPI_RESID) {
+                    const half4 rr = *reinterpret_cast<const half4*>(a.resid + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (float)rr[e] + y[e];
+                }
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)y[e];
+                *reinterpret_cast<half4*>(a.out + off) = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+static int launch_gemm(const GemmArgs& a, int w_bits, hipStream_t st) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK;
+    static_assert(LDS >= 4 * BN * 4, "epilogue parameter staging must fit");
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    dim3 grid(MT * NTl), block(NT);
+    hipError_t e;
+    if (w_bits <= 4) {
+        auto k = gemm_i8_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LDS);
+        if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, LDS, st, a);
+    } else {
+        auto k = gemm_i8_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LDS);
+        if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, LDS, st, a);
+    }
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    return vq_check_launch();
+}
+
+extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R, const void* wq,
+                          const float* sw, const int32_t* zw, const int32_t* cs, const float* bias, void* out,
+                          int ldo, const void* resid, const float* gate, int rows_per_gate, int M, int N, int K,
+                          int Kp, int w_bits, int epilogue, int variant, void* stream) {
+    if (!xq || !sx || !zx || !R || !wq || !sw || !zw || !cs || !out) return VQ_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0) return VQ_EINVAL;
+    if (Kp % 128 != 0 || Kp < K || N % 4 != 0 || ldo % 4 != 0 || ldo < N) return VQ_ESHAPE;
+    if (w_bits < 2 || w_bits > 8) return VQ_EUNSUP;
+    if (epilogue < VQ_EPI_NONE || epilogue > VQ_EPI_RESID) return VQ_EUNSUP;
+    if ((epilogue == VQ_EPI_GATE_RESID || epilogue == VQ_EPI_RESID) && !resid) return VQ_EINVAL;
+    if (epilogue == VQ_EPI_GATE_RESID && (!gate || rows_per_gate <= 0)) return VQ_EINVAL;
+    // 24-bit multiplies in the epilogue: |R| < 2^23 needs K <= 2^14
+    if (K > 16384) return VQ_ESHAPE;
+    GemmArgs a{xq, sx, zx, R, (const uint8_t*)wq, sw, zw, cs, bias, (half_t*)out, (const half_t*)resid, gate,
+               ldo, rows_per_gate > 0 ? rows_per_gate : 1, M, N, K, Kp, epilogue};
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 0:  // default: 256 x 288 tile, BK 128, 8 waves along tokens
+            return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+        case 1:  // 256 x 288, BK 64
+            return launch_gemm<256, 288, 64, 8, 1>(a, w_bits, st);
+        case 2:  // 128 x 128 tile, 4 waves (2x2) - small problems / comparison
+            return launch_gemm<128, 128, 128, 2, 2>(a, w_bits, st);
+        case 3:  // 256 x 256, 8 waves (2x4): wave tile 128 x 64
+            return launch_gemm<256, 256, 128, 2, 4>(a, w_bits, st);
+        default:
+            return VQ_EUNSUP;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// MFMA lane-layout probe: out[i][j] = sum_k a[i][k] * b[j][k] for 32x32x32 int8, one wave,
+// using exactly the fragment/accumulator mapping the GEMM assumes.
+// ---------------------------------------------------------------------------
+__global__ void probe_mfma_i8_kernel(const int8_t* a, const int8_t* b, int32_t* out) {
+    const int lane = threadIdx.x;
+    const int4v af = *reinterpret_cast<const int4v*>(a + (lane & 31) * 32 + (lane >> 5) * 16);
+    const int4v bf = *reinterpret_cast<const int4v*>(b + (lane & 31) * 32 + (lane >> 5) * 16);
+    int16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // row of D = row of the A operand
+        const int j = lane & 31;                                  // col of D = row of the B operand
+        out[i * 32 + j] = acc[r];
+    }
+}
+
+extern "C" int vq_probe_mfma_i8(const int8_t* a, const int8_t* b, int32_t* out, void* stream) {
+    if (!a || !b || !out) return VQ_EINVAL;
+    hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, out);
+    return vq_check_launch();
+}

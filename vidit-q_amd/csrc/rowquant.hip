@@ -1,0 +1,415 @@
+// rowquant.hip - per-token dynamic activation quantizers for gfx950.
+//
+// HBM-bound kernels: one wave64 owns one token (all B batch rows of it, because
+// the reference shares a token's scale over the batch, base_quantizer.py:185),
+// 16-byte coalesced loads (8 fp16 / lane), min/max + row-sum by wavefront
+// shuffles, 8-byte int8 stores.  Algorithmic bytes per row of C channels:
+// 2*C read + Kp written (+12 B of per-row parameters).
+//
+// Replaces: DynamicActQuantizer.forward (qdiff/quantizer/dynamic_quantizer.py:16-45),
+// BaseQuantizer.init_quant_params token branch (base_quantizer.py:177-228),
+// nn.LayerNorm + t2i_modulate (opensora/models/stdit/stdit.py:103,124;
+// layers/blocks.py:51) and the smooth-quant division (qdiff/models/quant_layer.py:140).
+#include "vq_common.h"
+
+#define RQ_WAVES 4
+#define RQ_THREADS (RQ_WAVES * 64)
+
+__device__ __forceinline__ void store_codes8(int8_t* dst, const int q[8]) {
+    uint32_t lo = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) |
+                  ((uint32_t)(q[3] & 0xff) << 24);
+    uint32_t hi = (uint32_t)(q[4] & 0xff) | ((uint32_t)(q[5] & 0xff) << 8) | ((uint32_t)(q[6] & 0xff) << 16) |
+                  ((uint32_t)(q[7] & 0xff) << 24);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+}
+
+// ---------------------------------------------------------------------------
+// plain per-token quantizer (optional row-add and smooth division)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RQ_THREADS) void rowquant_kernel(
+    const half_t* __restrict__ x, const half_t* __restrict__ add_rows, int add_div, const float* __restrict__ s,
+    int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R,
+    float* __restrict__ zpf, int B, int n_tok, int C, int Kp, int n_bits, int32_t* status) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * RQ_WAVES + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int cx = (n_bits == 8) ? 128 : 0;
+    const half_t* addp = add_rows ? add_rows + (size_t)(tok / add_div) * C : nullptr;
+
+    // pass 1: min / max over the B rows of this token
+    float vmin = INFINITY, vmax = -INFINITY;
+    for (int b = 0; b < B; ++b) {
+        const half_t* row = x + ((size_t)b * n_tok + tok) * C;
+        for (int c0 = lane * 8; c0 < C; c0 += 512) {
+            half8 h = *reinterpret_cast<const half8*>(row + c0);
+            half8 a;
+            if (addp) a = *reinterpret_cast<const half8*>(addp + c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = (float)h[i];
+                if (addp) v += (float)a[i];
+                if (s) v = __fdiv_rn(v, s[c0 + i]);
+                vmin = fminf(vmin, v);
+                vmax = fmaxf(vmax, v);
+            }
+        }
+    }
+    vmin = wave_min_f(vmin);
+    vmax = wave_max_f(vmax);
+    float delta, zp;
+    bool small;
+    vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+    if (small && lane == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
+    const int izx = (int)zp - cx;
+
+    // pass 2: quantize (the row is L1/L2-hot)
+    for (int b = 0; b < B; ++b) {
+        const size_t r = (size_t)b * n_tok + tok;
+        const half_t* row = x + r * C;
+        int8_t* qrow = xq + r * Kp;
+        int rs = 0;
+        for (int c0 = lane * 8; c0 < Kp; c0 += 512) {
+            int q[8];
+            if (c0 < C) {
+                half8 h = *reinterpret_cast<const half8*>(row + c0);
+                half8 a;
+                if (addp) a = *reinterpret_cast<const half8*>(addp + c0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = (float)h[i];
+                    if (addp) v += (float)a[i];
+                    if (s) v = __fdiv_rn(v, s[c0 + i]);
+                    q[i] = (int)vq_code(v, delta, zp, qmax) - cx;
+                    rs += q[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = 0;
+            }
+            store_codes8(qrow + c0, q);
+        }
+        rs = wave_sum_i(rs);
+        if (lane == 0) {
+            sx[r] = delta;
+            zx[r] = izx;
+            R[r] = rs - C * izx;
+            if (zpf) zpf[r] = zp;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm(no affine) + AdaLN modulate + up to 3 smoothed per-token quantizers
+// ---------------------------------------------------------------------------
+#define LNQ_MAXB 8
+struct LnqOut {
+    const float* s[3];
+    int8_t* xq[3];
+    float* sx[3];
+    int32_t* zx[3];
+    int32_t* R[3];
+};
+
+template <int NOUT>
+__global__ __launch_bounds__(RQ_THREADS) void ln_modulate_rowquant_kernel(
+    const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
+    LnqOut o, half_t* __restrict__ xm_out, int B, int n_tok, int C, int Kp, int n_bits, int32_t* status) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * RQ_WAVES + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int cx = (n_bits == 8) ? 128 : 0;
+    const float invC = 1.0f / (float)C;
+
+    float mean[LNQ_MAXB], rstd[LNQ_MAXB];
+    float vmin[NOUT], vmax[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        vmin[j] = INFINITY;
+        vmax[j] = -INFINITY;
+    }
+#pragma unroll
+    for (int b = 0; b < LNQ_MAXB; ++b) {
+        if (b >= B) break;
+        const half_t* row = x + ((size_t)b * n_tok + tok) * C;
+        float sum = 0.f;
+        for (int c0 = lane * 8; c0 < C; c0 += 512) {
+            half8 h = *reinterpret_cast<const half8*>(row + c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += (float)h[i];
+        }
+        const float mu = wave_sum_f(sum) * invC;
+        float sq = 0.f;
+        for (int c0 = lane * 8; c0 < C; c0 += 512) {
+            half8 h = *reinterpret_cast<const half8*>(row + c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float d = (float)h[i] - mu;
+                sq += d * d;
+            }
+        }
+        const float var = wave_sum_f(sq) * invC;
+        const float rs_ = __fdiv_rn(1.0f, __fsqrt_rn(var + ln_eps));
+        mean[b] = mu;
+        rstd[b] = rs_;
+        const float* sh = shift + (size_t)b * C;
+        const float* sc = scale + (size_t)b * C;
+        for (int c0 = lane * 8; c0 < C; c0 += 512) {
+            half8 h = *reinterpret_cast<const half8*>(row + c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float y = ((float)h[i] - mu) * rs_;
+                float v = y * (1.0f + sc[c0 + i]) + sh[c0 + i];
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) {
+                    float u = o.s[j] ? __fdiv_rn(v, o.s[j][c0 + i]) : v;
+                    vmin[j] = fminf(vmin[j], u);
+                    vmax[j] = fmaxf(vmax[j], u);
+                }
+            }
+        }
+    }
+    float delta[NOUT], zp[NOUT];
+    int izx[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        bool small;
+        vq_minmax_to_params(wave_min_f(vmin[j]), wave_max_f(vmax[j]), qmax, delta[j], zp[j], small);
+        if (small && lane == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
+        izx[j] = (int)zp[j] - cx;
+    }
+#pragma unroll
+    for (int b = 0; b < LNQ_MAXB; ++b) {
+        if (b >= B) break;
+        const size_t r = (size_t)b * n_tok + tok;
+        const half_t* row = x + r * C;
+        const float* sh = shift + (size_t)b * C;
+        const float* sc = scale + (size_t)b * C;
+        const float mu = mean[b], rs_ = rstd[b];
+        int rsum[NOUT];
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) rsum[j] = 0;
+        for (int c0 = lane * 8; c0 < Kp; c0 += 512) {
+            int q[NOUT][8];
+            if (c0 < C) {
+                half8 h = *reinterpret_cast<const half8*>(row + c0);
+                half8 hm;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float y = ((float)h[i] - mu) * rs_;
+                    float v = y * (1.0f + sc[c0 + i]) + sh[c0 + i];
+                    hm[i] = (half_t)v;
+#pragma unroll
+                    for (int j = 0; j < NOUT; ++j) {
+                        float u = o.s[j] ? __fdiv_rn(v, o.s[j][c0 + i]) : v;
+                        q[j][i] = (int)vq_code(u, delta[j], zp[j], qmax) - cx;
+                        rsum[j] += q[j][i];
+                    }
+                }
+                if (xm_out) *reinterpret_cast<half8*>(xm_out + r * C + c0) = hm;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[j][i] = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) store_codes8(o.xq[j] + r * Kp + c0, q[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) {
+            int rs = wave_sum_i(rsum[j]);
+            if (lane == 0) {
+                o.sx[j][r] = delta[j];
+                o.zx[j][r] = izx[j];
+                o.R[j][r] = rs - C * izx[j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// exact fake-quant (quantize -> dequantize) incl. the global eps-fill rule
+// ---------------------------------------------------------------------------
+// stage A: per-token min (-> zp_out as scratch) and raw delta (-> delta_out);
+//          global min(delta) through atomicMin on the float bits (delta >= 0).
+__global__ __launch_bounds__(RQ_THREADS) void fq_stats_kernel(const half_t* __restrict__ x,
+                                                              float* __restrict__ delta_out,
+                                                              float* __restrict__ xmin_out, uint32_t* min_delta_bits,
+                                                              int B, int n_tok, int C, int n_bits) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * RQ_WAVES + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    float vmin = INFINITY, vmax = -INFINITY;
+    for (int b = 0; b < B; ++b) {
+        const half_t* row = x + ((size_t)b * n_tok + tok) * C;
+        for (int c0 = lane * 8; c0 < C; c0 += 512) {
+            half8 h = *reinterpret_cast<const half8*>(row + c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = (float)h[i];
+                vmin = fminf(vmin, v);
+                vmax = fmaxf(vmax, v);
+            }
+        }
+    }
+    vmin = fminf(wave_min_f(vmin), 0.0f);
+    vmax = fmaxf(wave_max_f(vmax), 0.0f);
+    const float qmax = (float)((1 << n_bits) - 1);
+    const float d = __fdiv_rn(vmax - vmin, qmax);
+    if (lane == 0) {
+        delta_out[tok] = d;
+        xmin_out[tok] = vmin;
+        atomicMin(min_delta_bits, __float_as_uint(d));
+    }
+}
+
+// stage B: finalize (delta, zp) per token given the global minimum.
+__global__ void fq_finalize_kernel(float* __restrict__ delta, float* __restrict__ zp_xmin,
+                                   const uint32_t* min_delta_bits, int n_tok, int32_t* status) {
+    const int tok = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tok >= n_tok) return;
+    const bool fill = __uint_as_float(*min_delta_bits) < VQ_EPS;  // base_quantizer.py:220-222
+    float d = fill ? VQ_EPS : delta[tok];
+    delta[tok] = d;
+    zp_xmin[tok] = rintf(__fdiv_rn(-zp_xmin[tok], d));  // :228
+    if (fill && tok == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
+}
+
+// stage C: elementwise quant->dequant.  n_param: 1 (tensor-wise) or n_tok.
+__global__ __launch_bounds__(256) void fq_apply_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
+                                                       uint8_t* __restrict__ codes, const float* __restrict__ delta,
+                                                       const float* __restrict__ zp, int n_param, size_t rows,
+                                                       int n_tok, int C, int n_bits) {
+    const float qmax = (float)((1 << n_bits) - 1);
+    const size_t chunks_per_row = (size_t)C / 8;
+    const size_t total = rows * chunks_per_row;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / chunks_per_row;
+        const int c0 = (int)(idx % chunks_per_row) * 8;
+        const int p = n_param == 1 ? 0 : (int)(r % n_tok);
+        const float d = delta[p], z = zp[p];
+        half8 h = *reinterpret_cast<const half8*>(x + r * C + c0);
+        half8 o;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float q = vq_code((float)h[i], d, z, qmax);
+            o[i] = (half_t)((q - z) * d);  // base_quantizer.py:143
+            uint32_t qi = (uint32_t)q;
+            if (i < 4) lo |= qi << (8 * i);
+            else hi |= qi << (8 * (i - 4));
+        }
+        if (out) *reinterpret_cast<half8*>(out + r * C + c0) = o;
+        if (codes) *reinterpret_cast<uint2*>(codes + r * C + c0) = make_uint2(lo, hi);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// AdaLN table: mod[b,j,c] = table[j,c] + t0[b, j*C + c]   (stdit.py:100-102)
+// ---------------------------------------------------------------------------
+__global__ void adaln_table_kernel(const half_t* __restrict__ table, const half_t* __restrict__ t0,
+                                   float* __restrict__ mod, int B, int J, int C) {
+    const int n = B * J * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int jc = i % (J * C);
+        mod[i] = (float)table[jc] + (float)t0[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, const float* s, int8_t* xq,
+                           float* sx, int32_t* zx, int32_t* R, float* zpf, int B, int n_tok, int C, int Kp,
+                           int n_bits, int32_t* status, void* stream) {
+    if (!x || !xq || !sx || !zx || !R) return VQ_EINVAL;
+    if (B <= 0 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
+    if (C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
+    if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
+    if (add_rows && (add_div <= 0 || n_add <= 0 || (n_tok + add_div - 1) / add_div > n_add)) return VQ_EINVAL;
+    dim3 grid((n_tok + RQ_WAVES - 1) / RQ_WAVES);
+    hipLaunchKernelGGL(rowquant_kernel, grid, dim3(RQ_THREADS), 0, (hipStream_t)stream, (const half_t*)x,
+                       (const half_t*)add_rows, add_div > 0 ? add_div : 1, s, xq, sx, zx, R, zpf, B, n_tok, C, Kp,
+                       n_bits, status);
+    return vq_check_launch();
+}
+
+extern "C" int vq_ln_modulate_rowquant(const void* x, const float* shift, const float* scale, float ln_eps, int n_out,
+                                       const float* const* s, int8_t* const* xq, float* const* sx,
+                                       int32_t* const* zx, int32_t* const* R, void* xm_out, int B, int n_tok, int C,
+                                       int Kp, int n_bits, int32_t* status, void* stream) {
+    if (!x || !shift || !scale || !xq || !sx || !zx || !R) return VQ_EINVAL;
+    if (n_out < 1 || n_out > 3 || B <= 0 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
+    if (B > LNQ_MAXB || C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
+    if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
+    LnqOut o;
+    for (int j = 0; j < 3; ++j) {
+        const bool on = j < n_out;
+        o.s[j] = (on && s) ? s[j] : nullptr;
+        o.xq[j] = on ? xq[j] : nullptr;
+        o.sx[j] = on ? sx[j] : nullptr;
+        o.zx[j] = on ? zx[j] : nullptr;
+        o.R[j] = on ? R[j] : nullptr;
+        if (on && (!o.xq[j] || !o.sx[j] || !o.zx[j] || !o.R[j])) return VQ_EINVAL;
+    }
+    dim3 grid((n_tok + RQ_WAVES - 1) / RQ_WAVES), block(RQ_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    const half_t* xh = (const half_t*)x;
+    half_t* xm = (half_t*)xm_out;
+    if (n_out == 1)
+        hipLaunchKernelGGL(ln_modulate_rowquant_kernel<1>, grid, block, 0, st, xh, shift, scale, ln_eps, o, xm, B,
+                           n_tok, C, Kp, n_bits, status);
+    else if (n_out == 2)
+        hipLaunchKernelGGL(ln_modulate_rowquant_kernel<2>, grid, block, 0, st, xh, shift, scale, ln_eps, o, xm, B,
+                           n_tok, C, Kp, n_bits, status);
+    else
+        hipLaunchKernelGGL(ln_modulate_rowquant_kernel<3>, grid, block, 0, st, xh, shift, scale, ln_eps, o, xm, B,
+                           n_tok, C, Kp, n_bits, status);
+    return vq_check_launch();
+}
+
+extern "C" int vq_fakequant_act(const void* x, void* out, uint8_t* codes, float* delta_out, float* zp_out,
+                                const float* delta_in, const float* zp_in, int n_param, int B, int n_tok, int C,
+                                int n_bits, int mode, float* scratch, int32_t* status, void* stream) {
+    if (!x || B <= 0 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
+    if (C % 8 != 0) return VQ_ESHAPE;
+    if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = (size_t)B * n_tok;
+    const float *d = delta_in, *z = zp_in;
+    int np = n_param;
+    if (mode == 0) {
+        if (!delta_out || !zp_out || !scratch) return VQ_EINVAL;
+        hipError_t e = hipMemsetAsync(scratch, 0x7f, sizeof(float), st);  // 0x7f7f7f7f = 3.39e38
+        if (e != hipSuccess) {
+            g_vq_last_hip_error = (int)e;
+            return VQ_ELAUNCH;
+        }
+        hipLaunchKernelGGL(fq_stats_kernel, dim3((n_tok + RQ_WAVES - 1) / RQ_WAVES), dim3(RQ_THREADS), 0, st,
+                           (const half_t*)x, delta_out, zp_out, (uint32_t*)scratch, B, n_tok, C, n_bits);
+        hipLaunchKernelGGL(fq_finalize_kernel, dim3((n_tok + 255) / 256), dim3(256), 0, st, delta_out, zp_out,
+                           (const uint32_t*)scratch, n_tok, status);
+        d = delta_out;
+        z = zp_out;
+        np = n_tok;
+    } else {
+        if (!d || !z || (np != 1 && np != n_tok)) return VQ_EINVAL;
+    }
+    size_t total = rows * (size_t)(C / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(fq_apply_kernel, dim3(blocks), dim3(256), 0, st, (const half_t*)x, (half_t*)out, codes, d, z,
+                       np, rows, n_tok, C, n_bits);
+    return vq_check_launch();
+}
+
+extern "C" int vq_adaln_table(const void* table, const void* t0, float* mod, int B, int J, int C, void* stream) {
+    if (!table || !t0 || !mod || B <= 0 || J <= 0 || C <= 0) return VQ_EINVAL;
+    int n = B * J * C;
+    hipLaunchKernelGGL(adaln_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)table, (const half_t*)t0, mod, B, J, C);
+    return vq_check_launch();
+}

@@ -1,0 +1,304 @@
+"""Tensor-level wrappers over the C ABI (include/viditq.h).
+
+PyTorch is plumbing here: device memory (torch tensors), the current HIP stream and nothing
+else.  Every function enqueues one or a few HIP kernels on ``torch.cuda.current_stream()`` and
+never synchronises.  There is no fallback path: a missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import EPI_GATE_RESID, EPI_GELU, EPI_NONE, EPI_RESID, VQError, check  # noqa: F401
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise VQError("%s must be a GPU tensor (no CPU fallback in the product path)" % name)
+    if t.dtype != dtype:
+        raise VQError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise VQError("%s must be contiguous" % name)
+    return t
+
+
+def pad128(k: int) -> int:
+    return (k + 127) // 128 * 128
+
+
+@dataclass
+class QAct:
+    """A per-token-quantized activation: int8 codes (minus cx) + per-row dequant terms."""
+    xq: torch.Tensor      # [rows, Kp] int8
+    sx: torch.Tensor      # [rows] fp32 delta
+    zx: torch.Tensor      # [rows] int32 zp - cx
+    R: torch.Tensor       # [rows] int32 rowsum - K*zx
+    K: int
+    n_bits: int = 8
+    zpf: Optional[torch.Tensor] = None
+
+    @property
+    def rows(self) -> int:
+        return self.xq.shape[0]
+
+    @property
+    def Kp(self) -> int:
+        return self.xq.shape[1]
+
+
+@dataclass
+class PackedWeight:
+    """An offline-quantized weight: packed codes + per-out-channel dequant terms."""
+    wq: torch.Tensor      # [N, Kp] int8  or [N, Kp/2] uint8 (n_bits <= 4)
+    sw: torch.Tensor      # [N] fp32
+    zw: torch.Tensor      # [N] int32
+    cs: torch.Tensor      # [N] int32
+    N: int
+    K: int
+    Kp: int
+    n_bits: int
+
+    def tensors(self):
+        return [self.wq, self.sw, self.zw, self.cs]
+
+
+def new_status(device) -> torch.Tensor:
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+# --------------------------------------------------------------------------- quantizers
+def rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
+             add_rows: Optional[torch.Tensor] = None, add_div: int = 1,
+             status: Optional[torch.Tensor] = None, want_zp: bool = False) -> QAct:
+    """Per-token dynamic quantizer of x [B, n_tok, C] fp16 (scales shared over B)."""
+    _req(x, torch.float16, "x")
+    assert x.dim() == 3
+    B, n_tok, Cc = x.shape
+    Kp = pad128(Cc)
+    rows = B * n_tok
+    dev = x.device
+    xq = torch.empty((rows, Kp), dtype=torch.int8, device=dev)
+    sx = torch.empty(rows, dtype=torch.float32, device=dev)
+    zx = torch.empty(rows, dtype=torch.int32, device=dev)
+    R = torch.empty(rows, dtype=torch.int32, device=dev)
+    zpf = torch.empty(rows, dtype=torch.float32, device=dev) if want_zp else None
+    if s is not None:
+        _req(s, torch.float32, "s")
+        assert s.numel() == Cc
+    n_add = 0
+    if add_rows is not None:
+        _req(add_rows, torch.float16, "add_rows")
+        n_add = add_rows.shape[0]
+    check(_L().vq_rowquant(_p(x), _p(add_rows), n_add, add_div, _p(s), _p(xq), _p(sx), _p(zx), _p(R), _p(zpf),
+                           B, n_tok, Cc, Kp, n_bits, _p(status), _stream()), "vq_rowquant")
+    return QAct(xq, sx, zx, R, Cc, n_bits, zpf)
+
+
+def ln_modulate_rowquant(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-6,
+                         smooth: Sequence[Optional[torch.Tensor]] = (None,), n_bits: int = 8,
+                         status: Optional[torch.Tensor] = None, want_xm: bool = False):
+    """LN(no affine) + (1+scale)*.+shift + per-token quant; one QAct per entry of ``smooth``."""
+    _req(x, torch.float16, "x")
+    B, n_tok, Cc = x.shape
+    _req(shift, torch.float32, "shift")
+    _req(scale, torch.float32, "scale")
+    assert shift.numel() == B * Cc and scale.numel() == B * Cc
+    n_out = len(smooth)
+    Kp = pad128(Cc)
+    rows = B * n_tok
+    dev = x.device
+    outs: List[QAct] = []
+    for _ in range(n_out):
+        outs.append(QAct(torch.empty((rows, Kp), dtype=torch.int8, device=dev),
+                         torch.empty(rows, dtype=torch.float32, device=dev),
+                         torch.empty(rows, dtype=torch.int32, device=dev),
+                         torch.empty(rows, dtype=torch.int32, device=dev), Cc, n_bits))
+    arr = C.c_void_p * 3
+
+    def mk(vals):
+        vals = list(vals) + [None] * (3 - len(vals))
+        return arr(*[C.c_void_p(v) if v is not None else None for v in vals])
+
+    for sm in smooth:
+        if sm is not None:
+            _req(sm, torch.float32, "smooth")
+    s_arr = mk([_p(sm) for sm in smooth])
+    xq_arr = mk([o.xq.data_ptr() for o in outs])
+    sx_arr = mk([o.sx.data_ptr() for o in outs])
+    zx_arr = mk([o.zx.data_ptr() for o in outs])
+    R_arr = mk([o.R.data_ptr() for o in outs])
+    xm = torch.empty_like(x) if want_xm else None
+    check(_L().vq_ln_modulate_rowquant(_p(x), _p(shift), _p(scale), float(eps), n_out,
+                                       C.cast(s_arr, C.c_void_p), C.cast(xq_arr, C.c_void_p),
+                                       C.cast(sx_arr, C.c_void_p), C.cast(zx_arr, C.c_void_p),
+                                       C.cast(R_arr, C.c_void_p), _p(xm), B, n_tok, Cc, Kp, n_bits,
+                                       _p(status), _stream()), "vq_ln_modulate_rowquant")
+    return (outs, xm) if want_xm else outs
+
+
+def fakequant_act(x: torch.Tensor, n_bits: int = 8, delta: Optional[torch.Tensor] = None,
+                  zp: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
+                  want_codes: bool = False):
+    """Exact fake-quant of x [B, n_tok, C] fp16.  delta/zp None -> per-token dynamic."""
+    _req(x, torch.float16, "x")
+    B, n_tok, Cc = x.shape
+    dev = x.device
+    out = torch.empty_like(x)
+    codes = torch.empty((B, n_tok, Cc), dtype=torch.uint8, device=dev) if want_codes else None
+    if delta is None:
+        d_out = torch.empty(n_tok, dtype=torch.float32, device=dev)
+        z_out = torch.empty(n_tok, dtype=torch.float32, device=dev)
+        scratch = torch.empty(1, dtype=torch.float32, device=dev)
+        check(_L().vq_fakequant_act(_p(x), _p(out), _p(codes), _p(d_out), _p(z_out), None, None, 0, B, n_tok, Cc,
+                                    n_bits, 0, _p(scratch), _p(status), _stream()), "vq_fakequant_act")
+        return out, codes, d_out, z_out
+    d = _req(delta.reshape(-1).contiguous(), torch.float32, "delta")
+    z = _req(zp.reshape(-1).contiguous(), torch.float32, "zp")
+    assert d.numel() == z.numel() and d.numel() in (1, n_tok)
+    check(_L().vq_fakequant_act(_p(x), _p(out), _p(codes), None, None, _p(d), _p(z), d.numel(), B, n_tok, Cc,
+                                n_bits, 1, None, _p(status), _stream()), "vq_fakequant_act")
+    return out, codes, d, z
+
+
+# --------------------------------------------------------------------------- weights
+def weight_minmax(W: torch.Tensor, n_bits: int, s: Optional[torch.Tensor] = None, force_eps: bool = False,
+                  status: Optional[torch.Tensor] = None):
+    """Per-out-channel min-max (delta, zp) of W*s, W [N,K] fp16."""
+    _req(W, torch.float16, "W")
+    N, K = W.shape
+    delta = torch.empty(N, dtype=torch.float32, device=W.device)
+    zp = torch.empty(N, dtype=torch.float32, device=W.device)
+    if s is not None:
+        _req(s, torch.float32, "s")
+    check(_L().vq_weight_minmax(_p(W), _p(s), _p(delta), _p(zp), N, K, n_bits, int(force_eps), _p(status),
+                                _stream()), "vq_weight_minmax")
+    return delta, zp
+
+
+def pack_weight(W: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, n_bits: int,
+                s: Optional[torch.Tensor] = None) -> PackedWeight:
+    """Quantize W*s on the (delta, zp) grid and pack for the int8 MFMA GEMM."""
+    _req(W, torch.float16, "W")
+    N, K = W.shape
+    Kp = pad128(K)
+    dev = W.device
+    d = _req(delta.reshape(-1).contiguous(), torch.float32, "delta")
+    z = _req(zp.reshape(-1).contiguous(), torch.float32, "zp")
+    assert d.numel() == N and z.numel() == N
+    if n_bits <= 4:
+        wq = torch.empty((N, Kp // 2), dtype=torch.uint8, device=dev)
+    else:
+        wq = torch.empty((N, Kp), dtype=torch.int8, device=dev)
+    sw = torch.empty(N, dtype=torch.float32, device=dev)
+    zw = torch.empty(N, dtype=torch.int32, device=dev)
+    cs = torch.empty(N, dtype=torch.int32, device=dev)
+    if s is not None:
+        _req(s, torch.float32, "s")
+    check(_L().vq_pack_weight(_p(W), _p(s), _p(d), _p(z), _p(wq), _p(sw), _p(zw), _p(cs), N, K, Kp, n_bits,
+                              _stream()), "vq_pack_weight")
+    return PackedWeight(wq, sw, zw, cs, N, K, Kp, n_bits)
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+            epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+            rows_per_gate: int = 0, variant: int = 0) -> torch.Tensor:
+    """out[M, N] fp16 = dequant(int8 MFMA(a, w)) + bias, with the fused epilogue."""
+    if a.K != w.K or a.Kp != w.Kp:
+        raise VQError("K mismatch: activation %d/%d weight %d/%d" % (a.K, a.Kp, w.K, w.Kp))
+    M, N = a.rows, w.N
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=a.xq.device)
+    else:
+        _req(out, torch.float16, "out")
+        assert out.dim() == 2 and out.shape[0] == M and out.shape[1] >= N
+    ldo = out.stride(0)
+    if bias is not None:
+        _req(bias, torch.float32, "bias")
+    if resid is not None:
+        _req(resid, torch.float16, "resid")
+        assert resid.stride(0) == ldo and resid.shape[0] == M
+    if gate is not None:
+        _req(gate, torch.float32, "gate")
+    check(_L().vq_gemm_i8(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs),
+                          _p(bias), _p(out), ldo, _p(resid), _p(gate), rows_per_gate, M, N, a.K, a.Kp,
+                          w.n_bits, epilogue, variant, _stream()), "vq_gemm_i8")
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, o, n_seq, Lq, Lk, H, D, q_seq_stride, q_tok_stride, kv_seq_stride, kv_tok_stride,
+             o_seq_stride, o_tok_stride, kv_off: Optional[torch.Tensor] = None, scale: Optional[float] = None):
+    """Flash attention over strided fp16 views (pointers are the tensors' data_ptr())."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+        if not t.is_cuda or t.dtype != torch.float16:
+            raise VQError("%s must be a GPU fp16 tensor" % n)
+    if kv_off is not None:
+        _req(kv_off, torch.int32, "kv_off")
+    scale = float(D) ** -0.5 if scale is None else float(scale)
+    check(_L().vq_attn_fwd(_p(q), _p(k), _p(v), _p(o), n_seq, Lq, Lk, H, D, q_seq_stride, q_tok_stride,
+                           kv_seq_stride, kv_tok_stride, o_seq_stride, o_tok_stride, _p(kv_off), scale, _stream()),
+          "vq_attn_fwd")
+    return o
+
+
+def attn_temporal(q, k, v, o, B, T, S, H, D, ld_in, ld_out, scale: Optional[float] = None):
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+        if not t.is_cuda or t.dtype != torch.float16:
+            raise VQError("%s must be a GPU fp16 tensor" % n)
+    scale = float(D) ** -0.5 if scale is None else float(scale)
+    check(_L().vq_attn_temporal(_p(q), _p(k), _p(v), _p(o), B, T, S, H, D, ld_in, ld_out, scale, _stream()),
+          "vq_attn_temporal")
+    return o
+
+
+# --------------------------------------------------------------------------- misc
+def adaln_table(table: torch.Tensor, t0: torch.Tensor) -> torch.Tensor:
+    """mod[B, J, C] fp32 = table[J, C] + t0[B, J*C]  (fp16 inputs)."""
+    _req(table, torch.float16, "table")
+    _req(t0, torch.float16, "t0")
+    J, Cc = table.shape
+    B = t0.shape[0]
+    assert t0.numel() == B * J * Cc
+    mod = torch.empty((B, J, Cc), dtype=torch.float32, device=table.device)
+    check(_L().vq_adaln_table(_p(table), _p(t0), _p(mod), B, J, Cc, _stream()), "vq_adaln_table")
+    return mod
+
+
+def cfg_ddim_step(cond: torch.Tensor, uncond: torch.Tensor, x: torch.Tensor, cfg: float, one_plus_k: float,
+                  A: float, Bc: float, abar_prev: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(cond, torch.float32, "cond")
+    _req(uncond, torch.float32, "uncond")
+    _req(x, torch.float32, "x")
+    n, Cc = x.shape[0], x.shape[1]
+    inner = x[0, 0].numel()
+    assert cond.shape[0] == n and cond.shape[1] == 2 * Cc and cond.shape == uncond.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_L().vq_cfg_ddim_step(_p(cond), _p(uncond), _p(x), _p(out), n, Cc, inner, float(cfg), float(one_plus_k),
+                                float(A), float(Bc), float(abar_prev), _stream()), "vq_cfg_ddim_step")
+    return out
+
+
+def probe_mfma_i8(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _req(a, torch.int8, "a")
+    _req(b, torch.int8, "b")
+    out = torch.empty((32, 32), dtype=torch.int32, device=a.device)
+    check(_L().vq_probe_mfma_i8(_p(a), _p(b), _p(out), _stream()), "vq_probe_mfma_i8")
+    return out
