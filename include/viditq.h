@@ -69,10 +69,14 @@ int vq_last_hip_error(void);
  * xq       [B*n_tok, Kp] int8 (code - cx, cx = 128 when n_bits==8 else 0)
  * sx       [B*n_tok] fp32 delta      zx [B*n_tok] int32 (zp - cx)
  * R        [B*n_tok] int32           zpf nullable [B*n_tok] fp32 (raw zero point)
+ * delta_in/zp_in nullable: a static, calibrated grid (ActQuantizer after init_done,
+ *          base_quantizer.py:129-144) of n_param = 1 (tensor-wise) or n_tok entries;
+ *          when given, no min/max is taken
  * status   nullable device int32 (bit VQ_ST_EPSFILL or-ed in)
  */
 int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, const float* s,
                 int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf,
+                const float* delta_in, const float* zp_in, int n_param,
                 int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
 
 /* Same, fused with LayerNorm(eps, no affine) + AdaLN modulate:
@@ -159,7 +163,7 @@ int vq_attn_temporal(const void* q, const void* k, const void* v, void* o,
                      float scale, void* stream);
 
 /* ---- small fused elementwise helpers ---------------------------------------
- * mod[b, j, c] = table[j, c] + t0[b, j*C + c]  (stdit.py:100-102), fp32 out. */
+ * mod[j, b, c] = table[j, c] + t0[b, j*C + c]  (stdit.py:100-102), fp32 out, chunk-major. */
 int vq_adaln_table(const void* table, const void* t0, float* mod, int B, int J, int C, void* stream);
 
 /* Fused CFG + DDIM(eta=0) update of the kept half of the batch: replaces the tail of

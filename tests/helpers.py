@@ -1,0 +1,41 @@
+"""Shared test helpers: golden loading, metrics."""
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_npz(name):
+    z = np.load(os.path.join(GOLD, name))
+    out = {}
+    for k in z.files:
+        v = z[k]
+        if v.dtype == np.float16:
+            v = v.astype(np.float32)
+        out[k] = torch.from_numpy(v) if v.dtype != np.float64 else v
+    return out
+
+
+def state_dict_of(gold):
+    return {k[3:]: v for k, v in gold.items() if k.startswith("sd/")}
+
+
+def quant_params_of(gold):
+    """{module_name: {buffer_name: tensor}} from the flattened ckpt.pth-schema arrays."""
+    out = {}
+    for k, v in gold.items():
+        if k.startswith("qp/"):
+            _, name, buf = k.split("/")
+            out.setdefault(name, {})[buf] = v
+    return out
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+TINY_CFG = dict(T=4, S=16, H=4, depth=2, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(4, 8, 8))
+FP_LAYERS = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]

@@ -297,7 +297,7 @@ def test_adaln_table_and_cfg_ddim(ops, dev):
     B, J, C = 2, 6, 64
     table, t0 = h16(J, C, seed=1), h16(B, J * C, seed=2)
     mod = ops.adaln_table(table.to(dev), t0.to(dev)).cpu()
-    assert torch.equal(mod, table.float()[None] + t0.float().reshape(B, J, C))
+    assert torch.equal(mod, (table.float()[None] + t0.float().reshape(B, J, C)).permute(1, 0, 2))
 
     n, Cc, inner = 2, 4, 16 * 8 * 8
     g = torch.Generator().manual_seed(5)

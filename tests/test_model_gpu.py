@@ -1,0 +1,225 @@
+"""GPU parity of the host-side operator API (QuantLayer family, QuantModel, STDiT, IDDPM) running
+on the HIP kernels, against golden vectors captured from the reference and against the oracle.
+
+Tolerances: the HIP path stores activations in fp16 between kernels (as the reference does on a
+GPU) while goldens/oracle are fp32 end to end, so per-layer outputs agree to fp16 rounding
+(rel-L2 < 1e-3, the north-star bound) and multi-layer outputs to a few 1e-3 because a 1-ulp
+difference can flip a quantization code downstream; each bound is stated at its assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import FP_LAYERS, TINY_CFG, load_npz, quant_params_of, rel_l2, state_dict_of
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(input_size=(4, 8, 8), depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
+
+
+def _cfgs(w_bits, smooth=None, mixed_precision=None):
+    from viditq_amd.config import to_config
+    wq = dict(n_bits=w_bits, per_group="channel", channel_dim=0, scale_method="min_max", round_mode="nearest")
+    if mixed_precision:
+        wq["mixed_precision"] = mixed_precision
+    sq = dict(enable=False)
+    if smooth:
+        sq = dict(enable=True, channel_wise_scale_type="momentum_act_max", momentum=0.95, **smooth)
+    aq = dict(n_bits=8, per_group="token", scale_method="min_max", round_mode="nearest_ste", running_stat=False,
+              dynamic=True, sym=False, n_spatial_token=16, n_temporal_token=4, n_prompt=12, smooth_quant=sq)
+    return to_config(wq), to_config(aq)
+
+
+def _build(gold, dev, w_bits, smooth=None, mixed_precision=None):
+    import viditq_amd  # noqa
+    from viditq_amd.qdiff.models import QuantModel
+    from viditq_amd.t2v import STDiT
+    m = STDiT(dtype=torch.float16, **TINY)
+    missing = m.load_state_dict(state_dict_of(gold), strict=True)
+    m = m.half().to(dev).eval()
+    wq, aq = _cfgs(w_bits, smooth, mixed_precision)
+    qnn = QuantModel(m, wq, aq)
+    qnn.set_module_name_for_quantizer(qnn.model)
+    qnn.fp_layer_list = list(FP_LAYERS)
+    qp = {name: [bufs, {}] for name, bufs in quant_params_of(gold).items()}
+    for name, m_ in qnn.model.named_modules():                 # quantizers never run in the reference keep None
+        pass
+    full = {}
+    from viditq_amd.qdiff.quantizer import BaseQuantizer
+    for mod in qnn.model.modules():
+        if isinstance(mod, BaseQuantizer):
+            full[mod.module_name] = qp.get(mod.module_name, [{}, {}])
+    qnn.set_quant_params_dict(full)                            # the ckpt.pth schema (quant_model.py:242-269)
+    qnn.set_quant_init_done("weight")
+    qnn.set_quant_init_done("activation")
+    qnn.set_quant_state(True, True)
+    qnn.cfg_split = True
+    return qnn
+
+
+# ----------------------------------------------------------------------------- layers vs reference goldens
+@pytest.mark.parametrize("name,cls_name", [("mlp", "QuantLayer"), ("spatial", "QuantSpatialAttnLinear"),
+                                           ("temporal", "QuantTemporalAttnLinear"),
+                                           ("cross_q", "QuantCrossAttnLinear"), ("cross_kv", "QuantCrossAttnLinear"),
+                                           ("bigk", "QuantLayer")])
+def test_quant_layers_match_reference(dev, ops, name, cls_name):
+    from viditq_amd.qdiff import models as qm
+    g = load_npz("layer_kats.npz")
+    W, b, x, y = g[name + "_W"], g[name + "_b"], g[name + "_x"], g[name + "_y"]
+    lin = torch.nn.Linear(W.shape[1], W.shape[0])
+    lin.weight.data, lin.bias.data = W.clone(), b.clone()
+    lin = lin.half().to(dev)
+    wq, aq = _cfgs(8)
+    layer = getattr(qm, cls_name)(lin, wq, aq)
+    layer.weight_quantizer.module_name = "w"
+    # PTQ flow of the reference: weight-only state initialises the weight quantizer (simulation route)
+    layer.set_quant_state(True, False)
+    y_w = layer(x.half().to(dev))
+    layer.weight_quantizer.init_done = True
+    layer.act_quantizer.init_done = True
+    if name + "_wdelta" in g:
+        assert torch.equal(layer.weight_quantizer.delta.cpu().reshape(-1), g[name + "_wdelta"].reshape(-1))
+    layer.set_quant_state(True, True)
+    assert layer.int_route_ok()
+    out = layer(x.half().to(dev))                               # integer route
+    assert out.shape == y.shape and out.dtype == torch.float16
+    assert rel_l2(out.cpu().float(), y) < 1e-3                  # fp16 output rounding
+    # simulation route (fake-quant kernels + fp GEMM) gives the same numbers
+    layer.act_quantizer.status = None
+    layer._can_pack = lambda: False
+    out_sim = layer(x.half().to(dev))
+    assert rel_l2(out_sim.cpu().float(), y) < 2e-3              # fp16 GEMM inputs
+
+
+def test_smooth_quant_two_ranges_w4_matches_reference(dev, ops):
+    from viditq_amd.qdiff import models as qm
+    g = load_npz("layer_kats.npz")
+    W, b, x = g["sq_W"], g["sq_b"], g["sq_x"]
+    lin = torch.nn.Linear(64, 48)
+    lin.weight.data, lin.bias.data = W.clone(), b.clone()
+    lin = lin.half().to(dev)
+    wq, aq = _cfgs(4, smooth=dict(alpha=[0.11, 0.25], timerange=[[0, 500], [501, 1000]]))
+    layer = qm.QuantSpatialAttnLinear(lin, wq, aq)
+    layer.weight_quantizer.module_name = "w"
+    layer.act_quantizer.act_scale = g["sq_act_scale"].to(dev)
+    layer.set_quant_state(True, False)
+    for t in (0, 501):                                          # ptq.py:266-293: one forward per range start
+        layer.cur_timestep_id = t
+        layer(x.half().to(dev))
+    layer.weight_quantizer.init_done = True
+    layer.act_quantizer.init_done = True
+    assert torch.equal(layer.weight_quantizer.delta_list.cpu(), g["sq_delta_list"])
+    assert torch.equal(layer.weight_quantizer.delta.cpu().reshape(-1), g["sq_wdelta"].reshape(-1))
+    layer.set_quant_state(True, True)
+    for t in (100, 800):
+        layer.cur_timestep_id = t
+        out = layer(x.half().to(dev))
+        assert rel_l2(out.cpu().float(), g["sq_y_t%d" % t]) < 1e-3
+    assert len([k for k in layer._packed if isinstance(k[0], int)]) == 2   # one int4 copy per time-range
+    assert layer.packed_weight(0).wq.dtype == torch.uint8 and layer.packed_weight(0).wq.shape == (48, 64)
+
+
+# ----------------------------------------------------------------------------- tiny STDiT vs reference goldens
+def test_tiny_stdit_w8a8_fused_path(dev, ops):
+    g = load_npz("tiny_stdit_w8a8.npz")
+    qnn = _build(g, dev, 8)
+    assert all(b.fused_ok() for b in qnn.model.blocks)
+    x, y, mask, t = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev), g["t"].to(dev)
+    blocks = []
+    hooks = []
+    import viditq_amd.t2v.stdit as st
+    orig = st.STDiTBlock.forward_fused
+
+    def spy(self, x2, *a, **k):
+        r = orig(self, x2, *a, **k)
+        blocks.append(x2.clone())
+        return r
+    st.STDiTBlock.forward_fused = spy
+    try:
+        cond = qnn(x, t, y[:1], mask=mask)
+    finally:
+        st.STDiTBlock.forward_fused = orig
+    # block outputs: fp16 storage between ~20 kernels, code flips downstream -> 3e-3
+    for i, bk in enumerate(blocks):
+        assert rel_l2(bk.cpu().float().reshape(1, 64, 64), g["w8a8_block%d" % i]) < 3e-3
+    assert cond.dtype == torch.float32 and cond.shape == g["w8a8_cond"].shape
+    assert rel_l2(cond.cpu(), g["w8a8_cond"]) < 5e-3
+    assert rel_l2(qnn(x, t, y[1:], mask=mask).cpu(), g["w8a8_uncond"]) < 5e-3
+    joint = qnn(torch.cat([x, x]), torch.cat([t, t]), y, mask=mask)   # cfg_split False: scales shared over B=2
+    assert rel_l2(joint.cpu(), g["w8a8_joint"]) < 5e-3
+    assert qnn.check_status() == 0
+    # the yardstick: quantization error itself (vs the FP model) is an order of magnitude larger
+    assert rel_l2(g["w8a8_cond"], g["fp_cond"]) > 5 * rel_l2(cond.cpu(), g["w8a8_cond"])
+
+
+def test_tiny_stdit_layerwise_equals_fused(dev, ops):
+    g = load_npz("tiny_stdit_w8a8.npz")
+    qnn = _build(g, dev, 8)
+    x, y, mask, t = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev), g["t"].to(dev)
+    fused = qnn(x, t, y[:1], mask=mask)
+    import viditq_amd.t2v.stdit as st
+    orig = st.STDiTBlock.fused_ok
+    st.STDiTBlock.fused_ok = lambda self: False
+    try:
+        layerwise = qnn(x, t, y[:1], mask=mask)
+    finally:
+        st.STDiTBlock.fused_ok = orig
+    assert rel_l2(layerwise.cpu(), fused.cpu()) < 5e-3
+    assert rel_l2(layerwise.cpu(), g["w8a8_cond"]) < 5e-3
+    qnn.set_quant_state(False, False)                           # FP model through the layerwise route
+    assert rel_l2(qnn(x, t, y[:1], mask=mask).cpu(), g["fp_cond"]) < 3e-3
+
+
+def test_tiny_stdit_w4a8_timerange_and_mixed_precision(dev, ops):
+    g = load_npz("tiny_stdit_w4a8.npz")
+    qnn = _build(g, dev, 4, smooth=dict(alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]]),
+                 mixed_precision=[4, 6, 8])
+    qnn.set_layer_smooth_quant(model=qnn, module_name_list=FP_LAYERS, smooth_quant=False,
+                               smooth_quant_running_stat=False)
+    assert all(b.fused_ok() for b in qnn.model.blocks)
+    x, y, mask = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev)
+    for tv in (721, 300):
+        out = qnn(x, torch.tensor([tv], device=dev), y[:1], mask=mask)
+        assert rel_l2(out.cpu(), g["w4a8_cond_t%d" % tv]) < 1e-2   # 4-bit weights: larger steps, same flips
+    qnn.load_bitwidth_config(qnn, {"model.blocks.0.mlp.fc1": 8, "model.blocks.1.attn.q": 8}, "weight")
+    out = qnn(x, torch.tensor([721], device=dev), y[:1], mask=mask)
+    assert rel_l2(out.cpu(), g["w4a8_mp_cond_t721"]) < 1e-2
+    assert qnn.model.blocks[0].mlp.fc1.packed_weight(1).n_bits == 8
+
+
+def test_ddim_loop_matches_reference_trajectory(dev, ops):
+    from viditq_amd.t2v import IDDPM
+    g = load_npz("tiny_stdit_w8a8.npz")
+    qnn = _build(g, dev, 8)
+    sch = IDDPM(num_sampling_steps=3, cfg_scale=4.0)
+    assert sch.timestep_map == [int(v) for v in g["ddim_timestep_map"]]
+    assert np.allclose(sch.alphas_cumprod, g["ddim_acp"], rtol=1e-14)
+    s100 = IDDPM(num_sampling_steps=100)
+    assert s100.timestep_map == [int(v) for v in g["tmap100"]] and np.allclose(s100.alphas_cumprod, g["acp100"], rtol=1e-14)
+    z = g["ddim_z"].to(dev)
+    out = sch.ddim_sample_loop(qnn, z, dict(y=g["y"].half().to(dev), mask=g["mask"].to(dev)))
+    assert rel_l2(out.cpu(), g["ddim_final"]) < 1e-2            # 6 quantized forwards chained
+
+
+def test_block_matches_oracle_at_xl_width(dev, ops):
+    """One STDiT-XL/2-width block (C=1152, 16 heads of 72, mlp 4608) at reduced token count
+    (T=4, S=64) through the fused path vs the oracle on identical weights."""
+    import viditq_amd  # noqa
+    from viditq_amd import synth
+    from viditq_amd.config import loads_yaml
+    from oracle import stdit_ref as sr
+    m = synth.build_stdit(dev, depth=1, input_size=(4, 16, 16), model_max_length=24, caption_channels=64, seed=3)
+    cfg = loads_yaml(synth.W8A8_DYNAMIC)
+    qnn = synth.quantize_model(m, cfg)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 4, 4, 16, 16, generator=g).to(dev)
+    y = (torch.randn(1, 1, 24, 64, generator=g) * 0.3).half().to(dev)
+    mask = torch.zeros(1, 24, dtype=torch.int64)
+    mask[0, :17] = 1
+    t = torch.tensor([500], device=dev)
+    out = qnn(x, t, y, mask=mask.to(dev))
+    sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items() if "weight_quantizer" not in k
+          and "act_quantizer" not in k}
+    cfgd = dict(T=4, S=64, H=16, depth=1, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(4, 16, 16))
+    ref = sr.stdit_forward(sd, cfgd, x.cpu().half().float(), t.cpu(), y.cpu().float(), mask, sr.QSpec(w_bits=8))
+    assert rel_l2(out.cpu(), ref) < 5e-3

@@ -1,0 +1,127 @@
+"""Pins the oracle (oracle/) against golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  Bit-exact where the arithmetic is elementwise fp32; F.linear /
+attention outputs to 1e-5 (summation order of the fp32 GEMM differs between shapes/threads)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TINY_CFG, load_npz, quant_params_of, rel_l2, state_dict_of
+from oracle import fakequant as fq
+from oracle import stdit_ref as sr
+
+
+def test_weight_quantizer_kats():
+    g = load_npz("quantizer_kats.npz")
+    W = g["w"]
+    for nb in (4, 6, 8):
+        d, z = fq.weight_params(W, nb)
+        assert torch.equal(d, g["w_delta_b%d" % nb]) and torch.equal(z, g["w_zp_b%d" % nb])
+        assert torch.equal(fq.weight_fakequant(W, d, z, nb)[1], g["w_dq_b%d" % nb])
+    # mixed precision: a grid per bit-width; after bitwidth_refactor(8) only the clamp widens
+    for i, nb in enumerate((4, 6, 8)):
+        d, z = fq.weight_params(W, nb)
+        assert torch.equal(d, g["w_mp_delta_list"][i, 0]) and torch.equal(z, g["w_mp_zp_list"][i, 0])
+    d4, z4 = fq.weight_params(W, 4)
+    assert torch.equal(fq.weight_fakequant(W, d4, z4, 4)[1], g["w_mp_dq4"])
+    assert torch.equal(fq.weight_fakequant(W, d4, z4, 8)[1], g["w_mp_dq8_on_4bit_grid"])
+
+
+def test_activation_quantizer_kats():
+    g = load_npz("quantizer_kats.npz")
+    for B in (1, 2):
+        codes, dq, d, z, eps = fq.dyn_act_quant(g["a_x_B%d" % B], 8)
+        assert not eps
+        assert torch.equal(d, g["a_delta_B%d" % B]) and torch.equal(z, g["a_zp_B%d" % B])
+        assert torch.equal(dq, g["a_dq_B%d" % B])
+    codes, dq, d, z, eps = fq.dyn_act_quant(g["eps_x"], 8)      # global eps fill (base_quantizer.py:220-222)
+    assert eps and torch.all(d == 1e-6)
+    assert torch.equal(d, g["eps_delta"]) and torch.equal(z, g["eps_zp"]) and torch.equal(dq, g["eps_dq"])
+    d, z = fq.tensor_params(g["st_x"], 8)
+    assert torch.equal(d.reshape(1, 1, 1), g["st_delta"]) and torch.equal(z.reshape(1, 1, 1), g["st_zp"])
+    assert torch.equal(fq.static_act_quant(g["st_x"], d, z, 8)[1], g["st_dq"])
+
+
+@pytest.mark.parametrize("name,view", [("mlp", None), ("spatial", (2, 64)), ("temporal", (2, 64)),
+                                       ("cross_q", None), ("cross_kv", None), ("bigk", None)])
+def test_layer_kats(name, view):
+    g = load_npz("layer_kats.npz")
+    x, W, b, y = g[name + "_x"], g[name + "_W"], g[name + "_b"], g[name + "_y"]
+    x3 = x if view is None else x.reshape(view[0], view[1], x.shape[-1])
+    out, parts = fq.quant_linear(x3, W, b, return_parts=True)
+    if name + "_wdelta" in g:
+        assert torch.equal(parts["w_delta"], g[name + "_wdelta"])
+    assert rel_l2(out.reshape(y.shape), y) < 1e-6
+
+
+def test_layer_smooth_quant_two_ranges_w4():
+    g = load_npz("layer_kats.npz")
+    x, W, b = g["sq_x"], g["sq_W"], g["sq_b"]
+    act_scale, alpha, tr = g["sq_act_scale"], [0.11, 0.25], [[0, 500], [501, 1000]]
+    s0 = fq.smooth_scale(act_scale[0], W, alpha[0])
+    d0, z0 = fq.weight_params(W * s0, 4)
+    assert torch.equal(d0, g["sq_wdelta"]) and torch.equal(d0, g["sq_delta_list"][0, 0])
+    # the per-range grid exists in delta_list but forward keeps using range 0
+    s1 = fq.smooth_scale(act_scale[1], W, alpha[1])
+    assert torch.equal(fq.weight_params(W * s1, 4)[0], g["sq_delta_list"][0, 1])
+    for t in (100, 800):
+        r = fq.find_interval(tr, t)
+        s = fq.smooth_scale(act_scale[r], W, alpha[r])
+        out = fq.quant_linear(x.reshape(2, 64, 64), W, b, w_bits=4, w_delta=d0, w_zp=z0, smooth=s)
+        assert rel_l2(out.reshape(8, 16, 48), g["sq_y_t%d" % t]) < 1e-6
+
+
+def test_tiny_stdit_w8a8_forward_blocks_and_cfg_modes():
+    g = load_npz("tiny_stdit_w8a8.npz")
+    sd = state_dict_of(g)
+    x, y, mask, t = g["x"], g["y"], g["mask"], g["t"]
+    out = sr.stdit_forward(sd, TINY_CFG, x, t, y[:1], mask, sr.QSpec(quant=False))
+    assert rel_l2(out, g["fp_cond"]) < 1e-5
+    spec = sr.QSpec(w_bits=8)
+    out, blocks = sr.stdit_forward(sd, TINY_CFG, x, t, y[:1], mask, spec, return_blocks=True)
+    for i, bk in enumerate(blocks):
+        assert rel_l2(bk, g["w8a8_block%d" % i]) < 1e-5
+    assert rel_l2(out, g["w8a8_cond"]) < 1e-5
+    assert rel_l2(sr.stdit_forward(sd, TINY_CFG, x, t, y[1:], mask, spec), g["w8a8_uncond"]) < 1e-5
+    joint = sr.stdit_forward(sd, TINY_CFG, torch.cat([x, x]), torch.cat([t, t]), y, mask, spec)
+    assert rel_l2(joint, g["w8a8_joint"]) < 1e-5
+    # the weight grids the oracle derived are the ones in the reference's quant-param dict
+    qp = quant_params_of(g)
+    for name, (d, z) in spec.w_grid.items():
+        assert torch.equal(d, qp[name + ".weight_quantizer"]["delta"].reshape(d.shape))
+
+
+def test_tiny_stdit_ddim_trajectory_and_schedule():
+    g = load_npz("tiny_stdit_w8a8.npz")
+    sd = state_dict_of(g)
+    tmap, acp = sr.spaced_schedule(100)
+    assert tmap == [int(v) for v in g["tmap100"]]
+    assert np.allclose(acp, g["acp100"], rtol=1e-14, atol=0)
+    tmap3, acp3 = sr.spaced_schedule(3)
+    assert tmap3 == [int(v) for v in g["ddim_timestep_map"]] and np.allclose(acp3, g["ddim_acp"], rtol=1e-14)
+    spec = sr.QSpec(w_bits=8)
+    x, y, mask = g["ddim_z"], g["y"], g["mask"]
+    for i in (2, 1, 0):
+        t = torch.tensor([tmap3[i]])
+        cond = sr.stdit_forward(sd, TINY_CFG, x, t, y[:1], mask, spec)
+        unc = sr.stdit_forward(sd, TINY_CFG, x, t, y[1:], mask, spec)
+        x = sr.cfg_ddim_step(x, cond, unc, acp3, i, 4.0)
+    assert rel_l2(x, g["ddim_final"]) < 1e-4   # 3 steps of quantized forwards: rounding flips amplify ulps
+
+
+def test_tiny_stdit_w4a8_timerange_and_mixed_precision():
+    g = load_npz("tiny_stdit_w4a8.npz")
+    sd = state_dict_of(g)
+    qp = quant_params_of(g)
+    act_scale = {n[:-len(".act_quantizer")]: b["act_scale"] for n, b in qp.items()
+                 if n.endswith(".act_quantizer") and "act_scale" in b and n.startswith("blocks")}
+    assert len(act_scale) == 2 * 13
+    spec = sr.QSpec(w_bits=4, act_scale=act_scale, alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]])
+    x, y, mask = g["x"], g["y"], g["mask"]
+    for tv in (721, 300):
+        out = sr.stdit_forward(sd, TINY_CFG, x, torch.tensor([tv]), y[:1], mask, spec)
+        assert rel_l2(out, g["w4a8_cond_t%d" % tv]) < 1e-5
+    for name, (d, z) in spec.w_grid.items():   # grid = delta_list[bit_idx(4), range 0]
+        assert torch.equal(d, qp[name + ".weight_quantizer"]["delta"].reshape(d.shape))
+    spec.layer_w_bits = {"blocks.0.mlp.fc1": 8, "blocks.1.attn.q": 8}
+    out = sr.stdit_forward(sd, TINY_CFG, x, torch.tensor([721]), y[:1], mask, spec)
+    assert rel_l2(out, g["w4a8_mp_cond_t721"]) < 1e-5

@@ -21,7 +21,8 @@ SIGNATURES = {
     "vq_version": (_i, []),
     "vq_strerror": (C.c_char_p, [_i]),
     "vq_last_hip_error": (_i, []),
-    "vq_rowquant": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vq_rowquant": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                         _i, _i, _i, _i, _i, _vp, _vp]),
     "vq_ln_modulate_rowquant": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _i, _i, _vp, _vp]),
     "vq_fakequant_act": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -29,7 +29,8 @@ __device__ __forceinline__ void store_codes8(int8_t* dst, const int q[8]) {
 __global__ __launch_bounds__(RQ_THREADS) void rowquant_kernel(
     const half_t* __restrict__ x, const half_t* __restrict__ add_rows, int add_div, const float* __restrict__ s,
     int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R,
-    float* __restrict__ zpf, int B, int n_tok, int C, int Kp, int n_bits, int32_t* status) {
+    float* __restrict__ zpf, const float* __restrict__ delta_in, const float* __restrict__ zp_in, int n_param,
+    int B, int n_tok, int C, int Kp, int n_bits, int32_t* status) {
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * RQ_WAVES + (threadIdx.x >> 6);
     if (tok >= n_tok) return;
@@ -37,9 +38,9 @@ __global__ __launch_bounds__(RQ_THREADS) void rowquant_kernel(
     const int cx = (n_bits == 8) ? 128 : 0;
     const half_t* addp = add_rows ? add_rows + (size_t)(tok / add_div) * C : nullptr;
 
-    // pass 1: min / max over the B rows of this token
+    // pass 1: min / max over the B rows of this token (skipped for a static, calibrated grid)
     float vmin = INFINITY, vmax = -INFINITY;
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < (delta_in ? 0 : B); ++b) {
         const half_t* row = x + ((size_t)b * n_tok + tok) * C;
         for (int c0 = lane * 8; c0 < C; c0 += 512) {
             half8 h = *reinterpret_cast<const half8*>(row + c0);
@@ -58,9 +59,14 @@ __global__ __launch_bounds__(RQ_THREADS) void rowquant_kernel(
     vmin = wave_min_f(vmin);
     vmax = wave_max_f(vmax);
     float delta, zp;
-    bool small;
-    vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
-    if (small && lane == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
+    if (delta_in) {  // ActQuantizer after init_done (base_quantizer.py:129-144)
+        delta = delta_in[n_param == 1 ? 0 : tok];
+        zp = zp_in[n_param == 1 ? 0 : tok];
+    } else {
+        bool small;
+        vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+        if (small && lane == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
+    }
     const int izx = (int)zp - cx;
 
     // pass 2: quantize (the row is L1/L2-hot)
@@ -308,14 +314,15 @@ __global__ __launch_bounds__(256) void fq_apply_kernel(const half_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// AdaLN table: mod[b,j,c] = table[j,c] + t0[b, j*C + c]   (stdit.py:100-102)
+// AdaLN table: mod[j,b,c] = table[j,c] + t0[b, j*C + c]   (stdit.py:100-102); [J][B][C] so that
+// every chunk (shift/scale/gate) is a contiguous [B, C] fp32 matrix
 // ---------------------------------------------------------------------------
 __global__ void adaln_table_kernel(const half_t* __restrict__ table, const half_t* __restrict__ t0,
                                    float* __restrict__ mod, int B, int J, int C) {
     const int n = B * J * C;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int jc = i % (J * C);
-        mod[i] = (float)table[jc] + (float)t0[i];
+        const int c = i % C, b = (i / C) % B, j = i / (C * B);
+        mod[i] = (float)table[j * C + c] + (float)t0[(size_t)b * J * C + j * C + c];
     }
 }
 
@@ -323,17 +330,19 @@ __global__ void adaln_table_kernel(const half_t* __restrict__ table, const half_
 // C ABI
 // ---------------------------------------------------------------------------
 extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, const float* s, int8_t* xq,
-                           float* sx, int32_t* zx, int32_t* R, float* zpf, int B, int n_tok, int C, int Kp,
-                           int n_bits, int32_t* status, void* stream) {
+                           float* sx, int32_t* zx, int32_t* R, float* zpf, const float* delta_in,
+                           const float* zp_in, int n_param, int B, int n_tok, int C, int Kp, int n_bits,
+                           int32_t* status, void* stream) {
     if (!x || !xq || !sx || !zx || !R) return VQ_EINVAL;
+    if (delta_in && (!zp_in || (n_param != 1 && n_param != n_tok))) return VQ_EINVAL;
     if (B <= 0 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
     if (C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
     if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
     if (add_rows && (add_div <= 0 || n_add <= 0 || (n_tok + add_div - 1) / add_div > n_add)) return VQ_EINVAL;
     dim3 grid((n_tok + RQ_WAVES - 1) / RQ_WAVES);
     hipLaunchKernelGGL(rowquant_kernel, grid, dim3(RQ_THREADS), 0, (hipStream_t)stream, (const half_t*)x,
-                       (const half_t*)add_rows, add_div > 0 ? add_div : 1, s, xq, sx, zx, R, zpf, B, n_tok, C, Kp,
-                       n_bits, status);
+                       (const half_t*)add_rows, add_div > 0 ? add_div : 1, s, xq, sx, zx, R, zpf, delta_in, zp_in,
+                       n_param, B, n_tok, C, Kp, n_bits, status);
     return vq_check_launch();
 }
 

@@ -85,8 +85,10 @@ def new_status(device) -> torch.Tensor:
 # --------------------------------------------------------------------------- quantizers
 def rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
              add_rows: Optional[torch.Tensor] = None, add_div: int = 1,
-             status: Optional[torch.Tensor] = None, want_zp: bool = False) -> QAct:
-    """Per-token dynamic quantizer of x [B, n_tok, C] fp16 (scales shared over B)."""
+             status: Optional[torch.Tensor] = None, want_zp: bool = False,
+             delta: Optional[torch.Tensor] = None, zp: Optional[torch.Tensor] = None) -> QAct:
+    """Per-token quantizer of x [B, n_tok, C] fp16 (scales shared over B): dynamic min-max, or on a
+    static calibrated grid when ``delta``/``zp`` (1 or n_tok entries) are given."""
     _req(x, torch.float16, "x")
     assert x.dim() == 3
     B, n_tok, Cc = x.shape
@@ -105,8 +107,14 @@ def rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
     if add_rows is not None:
         _req(add_rows, torch.float16, "add_rows")
         n_add = add_rows.shape[0]
+    n_param = 0
+    if delta is not None:
+        delta = _req(delta.reshape(-1).contiguous(), torch.float32, "delta")
+        zp = _req(zp.reshape(-1).contiguous(), torch.float32, "zp")
+        n_param = delta.numel()
     check(_L().vq_rowquant(_p(x), _p(add_rows), n_add, add_div, _p(s), _p(xq), _p(sx), _p(zx), _p(R), _p(zpf),
-                           B, n_tok, Cc, Kp, n_bits, _p(status), _stream()), "vq_rowquant")
+                           _p(delta), _p(zp), n_param, B, n_tok, Cc, Kp, n_bits, _p(status), _stream()),
+          "vq_rowquant")
     return QAct(xq, sx, zx, R, Cc, n_bits, zpf)
 
 
@@ -226,13 +234,15 @@ def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: 
     if out is None:
         out = torch.empty((M, N), dtype=torch.float16, device=a.xq.device)
     else:
-        _req(out, torch.float16, "out")
-        assert out.dim() == 2 and out.shape[0] == M and out.shape[1] >= N
+        if not out.is_cuda or out.dtype != torch.float16 or out.dim() != 2 or out.stride(1) != 1:
+            raise VQError("out must be a GPU fp16 2-D tensor with unit column stride")
+        assert out.shape[0] == M and out.shape[1] >= N
     ldo = out.stride(0)
     if bias is not None:
         _req(bias, torch.float32, "bias")
     if resid is not None:
-        _req(resid, torch.float16, "resid")
+        if not resid.is_cuda or resid.dtype != torch.float16 or resid.dim() != 2 or resid.stride(1) != 1:
+            raise VQError("resid must be a GPU fp16 2-D tensor with unit column stride")
         assert resid.stride(0) == ldo and resid.shape[0] == M
     if gate is not None:
         _req(gate, torch.float32, "gate")
@@ -270,13 +280,13 @@ def attn_temporal(q, k, v, o, B, T, S, H, D, ld_in, ld_out, scale: Optional[floa
 
 # --------------------------------------------------------------------------- misc
 def adaln_table(table: torch.Tensor, t0: torch.Tensor) -> torch.Tensor:
-    """mod[B, J, C] fp32 = table[J, C] + t0[B, J*C]  (fp16 inputs)."""
+    """mod[J, B, C] fp32 = table[J, C] + t0[B, J*C]  (fp16 inputs); mod[j] is a contiguous [B, C]."""
     _req(table, torch.float16, "table")
     _req(t0, torch.float16, "t0")
     J, Cc = table.shape
     B = t0.shape[0]
     assert t0.numel() == B * J * Cc
-    mod = torch.empty((B, J, Cc), dtype=torch.float32, device=table.device)
+    mod = torch.empty((J, B, Cc), dtype=torch.float32, device=table.device)
     check(_L().vq_adaln_table(_p(table), _p(t0), _p(mod), B, J, Cc, _stream()), "vq_adaln_table")
     return mod
 

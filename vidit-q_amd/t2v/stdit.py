@@ -1,0 +1,525 @@
+"""STDiT (OpenSORA v1.0) block and model forward on the gfx950 kernels.
+
+Module / parameter names mirror t2v/opensora/models/stdit/stdit.py and
+t2v/opensora/models/layers/blocks.py so that reference state-dicts, quant-param dicts
+(``ckpt.pth``) and the name routing of QuantModel apply unchanged:
+  blocks.{i}.attn.{q,k,v,proj}  attn_temp.{q,k,v,proj}  cross_attn.{q_linear,kv_linear,proj}
+  mlp.{fc1,fc2}  scale_shift_table   x_embedder.proj  t_embedder.mlp.{0,2}  t_block.1
+  y_embedder.y_proj.{fc1,fc2}  y_embedder.y_embedding  final_layer.{linear,scale_shift_table}
+
+Two routes through a block:
+* ``forward_fused`` (hot path; taken when every Linear of the block is on the integer route):
+  fused LN+modulate+quant -> int8 GEMMs with fused epilogues -> HIP attention, rows kept in one
+  canonical [B][T][S] order, residual stream updated in place.  ~20 kernels per block, no torch op.
+* ``forward_layerwise``: the reference's data flow (stdit.py:96-133) module by module - used for
+  FP inference and PTQ / calibration states; Linears are QuantLayers (or nn.Linear), attention is
+  the HIP kernel, the elementwise glue is torch.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..qdiff.models.quant_block import QuantAttention
+from ..qdiff.models.quant_layer import QuantLayer
+from ..qdiff.quantizer.dynamic_quantizer import DynamicActQuantizer
+
+
+def approx_gelu():
+    return nn.GELU(approximate="tanh")
+
+
+def t2i_modulate(x, shift, scale):
+    return x * (1 + scale) + shift
+
+
+# --------------------------------------------------------------------------- sincos embeddings
+def get_1d_sincos_pos_embed_from_grid(embed_dim, pos):
+    assert embed_dim % 2 == 0
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_1d_sincos_pos_embed(embed_dim, length, scale=1.0):
+    pos = np.arange(0, length)[..., None] / scale
+    return get_1d_sincos_pos_embed_from_grid(embed_dim, pos)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, scale=1.0, base_size=None):
+    if not isinstance(grid_size, tuple):
+        grid_size = (grid_size, grid_size)
+    grid_h = np.arange(grid_size[0], dtype=np.float32) / scale
+    grid_w = np.arange(grid_size[1], dtype=np.float32) / scale
+    if base_size is not None:
+        grid_h *= base_size / grid_size[0]
+        grid_w *= base_size / grid_size[1]
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0).reshape([2, 1, grid_size[1], grid_size[0]])
+    emb_h = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0])
+    emb_w = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])
+    return np.concatenate([emb_h, emb_w], axis=1)
+
+
+# --------------------------------------------------------------------------- small modules
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=approx_gelu, bias=True, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class PatchEmbed3D(nn.Module):
+    def __init__(self, patch_size=(2, 4, 4), in_chans=3, embed_dim=96):
+        super().__init__()
+        self.patch_size = patch_size
+        self.in_chans, self.embed_dim = in_chans, embed_dim
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        _, _, D, H, W = x.size()
+        if W % self.patch_size[2] != 0:
+            x = F.pad(x, (0, self.patch_size[2] - W % self.patch_size[2]))
+        if H % self.patch_size[1] != 0:
+            x = F.pad(x, (0, 0, 0, self.patch_size[1] - H % self.patch_size[1]))
+        if D % self.patch_size[0] != 0:
+            x = F.pad(x, (0, 0, 0, 0, 0, self.patch_size[0] - D % self.patch_size[0]))
+        x = self.proj(x)
+        return x.flatten(2).transpose(1, 2)  # BCTHW -> BNC
+
+
+class TimestepEmbedder(nn.Module):
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(),
+                                 nn.Linear(hidden_size, hidden_size, bias=True))
+        self.frequency_embedding_size = frequency_embedding_size
+
+    @staticmethod
+    def timestep_embedding(t, dim, max_period=10000):
+        half = dim // 2
+        freqs = torch.exp(-np.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+        args = t[:, None].float() * freqs.to(t.device)[None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        if dim % 2:
+            emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+        return emb
+
+    def forward(self, t, dtype):
+        t_freq = self.timestep_embedding(t, self.frequency_embedding_size)
+        if t_freq.dtype != dtype:
+            t_freq = t_freq.to(dtype)
+        return self.mlp(t_freq)
+
+
+class CaptionEmbedder(nn.Module):
+    def __init__(self, in_channels, hidden_size, uncond_prob, act_layer=approx_gelu, token_num=120):
+        super().__init__()
+        self.y_proj = Mlp(in_features=in_channels, hidden_features=hidden_size, out_features=hidden_size,
+                          act_layer=act_layer)
+        self.register_buffer("y_embedding", torch.randn(token_num, in_channels) / in_channels ** 0.5)
+        self.uncond_prob = uncond_prob
+
+    def forward(self, caption, train=False, force_drop_ids=None):
+        return self.y_proj(caption)
+
+
+class T2IFinalLayer(nn.Module):
+    def __init__(self, hidden_size, num_patch, out_channels):
+        super().__init__()
+        self.norm_final = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.linear = nn.Linear(hidden_size, num_patch * out_channels, bias=True)
+        self.scale_shift_table = nn.Parameter(torch.randn(2, hidden_size) / hidden_size ** 0.5)
+        self.out_channels = out_channels
+
+    def forward(self, x, t):
+        shift, scale = (self.scale_shift_table[None] + t[:, None]).chunk(2, dim=1)
+        x = t2i_modulate(self.norm_final(x), shift, scale)
+        return self.linear(x)
+
+
+class Attention(nn.Module):
+    """Self-attention with separate q/k/v Linears (blocks.py:113-195, ``separate_qkv=True``)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False):
+        super().__init__()
+        assert dim % num_heads == 0
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.separate_qkv = True
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.k = nn.Linear(dim, dim, bias=qkv_bias)
+        self.v = nn.Linear(dim, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.core = QuantAttention(num_heads, self.head_dim)
+
+    def forward(self, x):
+        """x [B', N', C] -> [B', N', C]: attention over N' within each of the B' sequences."""
+        Bp, Np, C = x.shape
+        q = self.q(x).reshape(Bp * Np, C)
+        k = self.k(x).reshape(Bp * Np, C)
+        v = self.v(x).reshape(Bp * Np, C)
+        dt = q.dtype
+        q, k, v = [t_.half().contiguous() for t_ in (q, k, v)]
+        o = torch.empty_like(q)
+        ops.attn_fwd(q, k, v, o, Bp, Np, Np, self.num_heads, self.head_dim, Np * C, C, Np * C, C, Np * C, C,
+                     scale=self.scale)
+        return self.proj(o.reshape(Bp, Np, C).to(dt))
+
+
+class MultiHeadCrossAttention(nn.Module):
+    """blocks.py:277-310: q from image tokens, k/v from the (mask-selected) prompt tokens."""
+
+    def __init__(self, d_model, num_heads):
+        super().__init__()
+        assert d_model % num_heads == 0
+        self.d_model, self.num_heads, self.head_dim = d_model, num_heads, d_model // num_heads
+        self.q_linear = nn.Linear(d_model, d_model)
+        self.kv_linear = nn.Linear(d_model, d_model * 2)
+        self.proj = nn.Linear(d_model, d_model)
+        self.core = QuantAttention(num_heads, self.head_dim)
+
+    def forward(self, x, cond, mask=None):
+        B, N, C = x.shape
+        dt = x.dtype
+        q = self.q_linear(x).reshape(B * N, C).half().contiguous()
+        kv = self.kv_linear(cond).reshape(-1, 2 * C).half().contiguous()
+        lens = mask if mask is not None else [kv.shape[0] // B] * B
+        off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=x.device)
+        o = self.core.cross(q, kv, off, B, N)
+        return self.proj(o.reshape(B, N, C).to(dt))
+
+
+# --------------------------------------------------------------------------- block
+class STDiTBlock(nn.Module):
+    def __init__(self, hidden_size, num_heads, d_s=None, d_t=None, mlp_ratio=4.0, **unused):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.norm1 = nn.LayerNorm(hidden_size, eps=1e-6, elementwise_affine=False)
+        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True)
+        self.cross_attn = MultiHeadCrossAttention(hidden_size, num_heads)
+        self.norm2 = nn.LayerNorm(hidden_size, eps=1e-6, elementwise_affine=False)
+        self.mlp = Mlp(in_features=hidden_size, hidden_features=int(hidden_size * mlp_ratio), act_layer=approx_gelu)
+        self.scale_shift_table = nn.Parameter(torch.randn(6, hidden_size) / hidden_size ** 0.5)
+        self.d_s, self.d_t = d_s, d_t
+        self.attn_temp = Attention(hidden_size, num_heads=num_heads, qkv_bias=True)
+        self._fused_w = {}
+
+    # ---- which route -----------------------------------------------------------------------
+    def hot_layers(self) -> List[nn.Module]:
+        return [self.attn.q, self.attn.k, self.attn.v, self.attn.proj,
+                self.attn_temp.q, self.attn_temp.k, self.attn_temp.v, self.attn_temp.proj,
+                self.cross_attn.q_linear, self.cross_attn.kv_linear, self.cross_attn.proj,
+                self.mlp.fc1, self.mlp.fc2]
+
+    def fused_ok(self) -> bool:
+        for m in self.hot_layers():
+            if not (isinstance(m, QuantLayer) and m.int_route_ok()):
+                return False
+            aq = m.act_quantizer
+            if not isinstance(aq, DynamicActQuantizer) and aq.per_group:
+                return False  # static per-token grids need the reference's [B, n_prompt, C] views
+        return True
+
+    def forward(self, x, y, t, mask=None, tpe=None):
+        if x.is_cuda and x.dtype == torch.float16 and self.fused_ok():
+            B, N, C = x.shape
+            x2 = x.reshape(B * N, C).clone()
+            lens = mask if mask is not None else [y.reshape(-1, C).shape[0] // B] * B
+            off = mask if isinstance(mask, torch.Tensor) else torch.tensor(
+                np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=x.device)
+            self.forward_fused(x2, y.reshape(-1, C).contiguous(), t.contiguous(), off, tpe, B)
+            return x2.reshape(B, N, C)
+        return self.forward_layerwise(x, y, t, mask, tpe)
+
+    # ---- reference data flow ---------------------------------------------------------------
+    def forward_layerwise(self, x, y, t, mask=None, tpe=None):
+        B, N, C = x.shape
+        T, S = self.d_t, self.d_s
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (
+            self.scale_shift_table[None] + t.reshape(B, 6, -1)).chunk(6, dim=1)
+        x_m = t2i_modulate(self.norm1(x), shift_msa, scale_msa)
+        x_s = x_m.reshape(B, T, S, C).reshape(B * T, S, C)
+        x_s = self.attn(x_s).reshape(B, T * S, C)
+        x = x + gate_msa * x_s
+        x_t = x.reshape(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
+        if tpe is not None:
+            x_t = x_t + tpe
+        x_t = self.attn_temp(x_t.contiguous())
+        x_t = x_t.reshape(B, S, T, C).permute(0, 2, 1, 3).reshape(B, T * S, C)
+        x = x + gate_msa * x_t
+        x = x + self.cross_attn(x, y, mask)
+        x = x + gate_mlp * self.mlp(t2i_modulate(self.norm2(x), shift_mlp, scale_mlp))
+        return x
+
+    # ---- hot path --------------------------------------------------------------------------
+    def _qkv_weights(self, att: Attention, r: int, svec):
+        """One [3C, K] packed weight when q/k/v share the activation codes and the bit-width."""
+        layers = (att.q, att.k, att.v)
+        pws = [l.packed_weight(r, s) for l, s in zip(layers, svec)]
+        if any(s is not None for s in svec) or len({p.n_bits for p in pws}) != 1:
+            return None, pws
+        key = (id(att), r, pws[0].n_bits)
+        ent = self._fused_w.get(key)
+        if ent is not None and all(a is b for a, b in zip(ent[1], pws)):
+            return ent[0], pws
+        cat = ops.PackedWeight(torch.cat([p.wq for p in pws]), torch.cat([p.sw for p in pws]),
+                               torch.cat([p.zw for p in pws]), torch.cat([p.cs for p in pws]),
+                               sum(p.N for p in pws), pws[0].K, pws[0].Kp, pws[0].n_bits)
+        bias = None
+        if layers[0].bias is not None:
+            bias = torch.cat([l.bias_f32() for l in layers])
+        self._fused_w[key] = ((cat, bias), pws)
+        return (cat, bias), pws
+
+    def forward_fused(self, x2, y2, t0, y_lens, tpe, B):
+        """In-place update of the residual stream x2 [B*T*S, C] fp16, rows ordered (b, t, s)."""
+        T, S, C = self.d_t, self.d_s, self.hidden_size
+        N = T * S
+        M = B * N
+        dev = x2.device
+        a1, a2, ca = self.attn, self.attn_temp, self.cross_attn
+        r, _ = a1.q._range_and_alpha()
+
+        def svec(layer):
+            rr, alpha = layer._range_and_alpha()
+            return layer.smooth_vector(rr, alpha)
+
+        mod = ops.adaln_table(self.scale_shift_table.detach(), t0.reshape(B, -1))   # [6, B, C] fp32
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = [mod[j] for j in range(6)]
+        x3 = x2.view(B, N, C)
+        st = a1.q.status
+
+        def qkv_proj(att, qas):
+            svs = [svec(l) for l in (att.q, att.k, att.v)]
+            fused, pws = self._qkv_weights(att, r, svs)
+            qkv = torch.empty((M, 3 * C), dtype=torch.float16, device=dev)
+            if fused is not None and len(qas) == 1:
+                ops.gemm_i8(qas[0], fused[0], bias=fused[1], out=qkv)
+            else:
+                for j, l in enumerate((att.q, att.k, att.v)):
+                    ops.gemm_i8(qas[j if len(qas) > 1 else 0], pws[j], bias=l.bias_f32(),
+                                out=qkv[:, j * C:(j + 1) * C])
+            return qkv
+
+        # ---- spatial branch: x += gate_msa * proj(attn(LN-mod(x)))          (stdit.py:103-109)
+        svs = [svec(l) for l in (a1.q, a1.k, a1.v)]
+        smooth = [None] if all(s is None for s in svs) else svs
+        qas = ops.ln_modulate_rowquant(x3, shift_msa, scale_msa, 1e-6, smooth=smooth,
+                                       n_bits=a1.q.act_quantizer.n_bits, status=st)
+        qkv = qkv_proj(a1, qas)
+        att_o = a1.core.spatial(qkv, B * T, S)
+        qa = a1.proj.quantize_input(att_o.view(B, N, C), svec(a1.proj))
+        ops.gemm_i8(qa, a1.proj.packed_weight(r, svec(a1.proj)), bias=a1.proj.bias_f32(), out=x2,
+                    epilogue=ops.EPI_GATE_RESID, resid=x2, gate=gate_msa, rows_per_gate=N)
+
+        # ---- temporal branch on the un-modulated x (+tpe in block 0)          (stdit.py:112-118)
+        svs = [svec(l) for l in (a2.q, a2.k, a2.v)]
+        tpe2 = None if tpe is None else tpe.reshape(T, C).contiguous()
+        if all(s is None for s in svs):
+            qas = [a2.q.quantize_input(x3, None, add_rows=tpe2, add_div=S)]
+        else:
+            qas = [l.quantize_input(x3, s, add_rows=tpe2, add_div=S) for l, s in zip((a2.q, a2.k, a2.v), svs)]
+        qkv = qkv_proj(a2, qas)
+        att_o = a2.core.temporal(qkv, B, T, S, out=att_o)
+        qa = a2.proj.quantize_input(att_o.view(B, N, C), svec(a2.proj))
+        ops.gemm_i8(qa, a2.proj.packed_weight(r, svec(a2.proj)), bias=a2.proj.bias_f32(), out=x2,
+                    epilogue=ops.EPI_GATE_RESID, resid=x2, gate=gate_msa, rows_per_gate=N)
+
+        # ---- cross attention: x += proj(attn(q(x), kv(y)))                    (stdit.py:121)
+        qa = ca.q_linear.quantize_input(x3, svec(ca.q_linear))
+        q = ops.gemm_i8(qa, ca.q_linear.packed_weight(r, svec(ca.q_linear)), bias=ca.q_linear.bias_f32())
+        ya = ca.kv_linear.quantize_input(y2.view(1, -1, C), svec(ca.kv_linear))
+        kv = ops.gemm_i8(ya, ca.kv_linear.packed_weight(r, svec(ca.kv_linear)), bias=ca.kv_linear.bias_f32())
+        att_o = ca.core.cross(q, kv, y_lens, B, N, out=att_o)
+        qa = ca.proj.quantize_input(att_o.view(B, N, C), svec(ca.proj))
+        ops.gemm_i8(qa, ca.proj.packed_weight(r, svec(ca.proj)), bias=ca.proj.bias_f32(), out=x2,
+                    epilogue=ops.EPI_RESID, resid=x2)
+
+        # ---- MLP: x += gate_mlp * fc2(gelu(fc1(LN-mod(x))))                   (stdit.py:124-128)
+        fc1, fc2 = self.mlp.fc1, self.mlp.fc2
+        qa = ops.ln_modulate_rowquant(x3, shift_mlp, scale_mlp, 1e-6, smooth=[svec(fc1)],
+                                      n_bits=fc1.act_quantizer.n_bits, status=st)[0]
+        h = ops.gemm_i8(qa, fc1.packed_weight(r, svec(fc1)), bias=fc1.bias_f32(), epilogue=ops.EPI_GELU)
+        qa = fc2.quantize_input(h.view(B, N, -1), svec(fc2))
+        ops.gemm_i8(qa, fc2.packed_weight(r, svec(fc2)), bias=fc2.bias_f32(), out=x2,
+                    epilogue=ops.EPI_GATE_RESID, resid=x2, gate=gate_mlp, rows_per_gate=N)
+        return x2
+
+
+# --------------------------------------------------------------------------- model
+class STDiT(nn.Module):
+    def __init__(self, input_size=(1, 32, 32), in_channels=4, patch_size=(1, 2, 2), hidden_size=1152, depth=28,
+                 num_heads=16, mlp_ratio=4.0, class_dropout_prob=0.1, pred_sigma=True, drop_path=0.0,
+                 no_temporal_pos_emb=False, caption_channels=4096, model_max_length=120, dtype=torch.float32,
+                 space_scale=1.0, time_scale=1.0, freeze=None, enable_flashattn=True, enable_layernorm_kernel=False,
+                 enable_sequence_parallelism=False, separate_qkv=True):
+        super().__init__()
+        assert not enable_sequence_parallelism, "sequence parallelism is training-only in the reference"
+        self.pred_sigma = pred_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if pred_sigma else in_channels
+        self.hidden_size, self.patch_size, self.input_size = hidden_size, patch_size, input_size
+        self.num_patches = int(np.prod([input_size[i] // patch_size[i] for i in range(3)]))
+        self.num_temporal = input_size[0] // patch_size[0]
+        self.num_spatial = self.num_patches // self.num_temporal
+        self.num_heads, self.dtype, self.depth, self.mlp_ratio = num_heads, dtype, depth, mlp_ratio
+        self.no_temporal_pos_emb = no_temporal_pos_emb
+        self.space_scale, self.time_scale = space_scale, time_scale
+        self.separate_qkv = True
+
+        self.register_buffer("pos_embed", self.get_spatial_pos_embed())
+        self.register_buffer("pos_embed_temporal", self.get_temporal_pos_embed())
+        self.x_embedder = PatchEmbed3D(patch_size, in_channels, hidden_size)
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.t_block = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+        self.y_embedder = CaptionEmbedder(in_channels=caption_channels, hidden_size=hidden_size,
+                                          uncond_prob=class_dropout_prob, act_layer=approx_gelu,
+                                          token_num=model_max_length)
+        self.blocks = nn.ModuleList([
+            STDiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio, d_t=self.num_temporal, d_s=self.num_spatial)
+            for _ in range(depth)])
+        self.final_layer = T2IFinalLayer(hidden_size, int(np.prod(patch_size)), self.out_channels)
+        self.initialize_weights()
+        self.initialize_temporal()
+        self._mask_cache = None
+
+    # ---- embeddings / init (stdit.py:367-442) ------------------------------------------------
+    def get_spatial_pos_embed(self):
+        g = self.input_size[1:]
+        pe = get_2d_sincos_pos_embed(self.hidden_size, (g[0] // self.patch_size[1], g[1] // self.patch_size[2]),
+                                     scale=self.space_scale)
+        return torch.from_numpy(pe).float().unsqueeze(0).requires_grad_(False)
+
+    def get_temporal_pos_embed(self):
+        pe = get_1d_sincos_pos_embed(self.hidden_size, self.input_size[0] // self.patch_size[0], scale=self.time_scale)
+        return torch.from_numpy(pe).float().unsqueeze(0).requires_grad_(False)
+
+    def initialize_temporal(self):
+        for block in self.blocks:
+            nn.init.constant_(block.attn_temp.proj.weight, 0)
+            nn.init.constant_(block.attn_temp.proj.bias, 0)
+
+    def initialize_weights(self):
+        def _basic_init(module):
+            if isinstance(module, nn.Linear):
+                torch.nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+        self.apply(_basic_init)
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        nn.init.normal_(self.t_block[1].weight, std=0.02)
+        nn.init.normal_(self.y_embedder.y_proj.fc1.weight, std=0.02)
+        nn.init.normal_(self.y_embedder.y_proj.fc2.weight, std=0.02)
+        for block in self.blocks:
+            nn.init.constant_(block.cross_attn.proj.weight, 0)
+            nn.init.constant_(block.cross_attn.proj.bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    # ---- prompt-token selection (stdit.py:272-301) --------------------------------------------
+    def _mask_select(self) -> bool:
+        aq = getattr(self.final_layer.linear, "act_quantizer", None)
+        if aq is not None and not isinstance(aq, DynamicActQuantizer) and aq.per_group == "token":
+            return False
+        return True
+
+    def _select_prompt_tokens(self, y, mask, C):
+        """Returns y [1, sum_L, C] and (host list y_lens, device int32 offsets).  The host copy of the
+        lengths (one sync, as mask.sum().tolist() in stdit.py:286) is cached per mask tensor."""
+        B = y.shape[0]
+        if mask is None:
+            lens = [y.shape[2]] * B
+            return y.squeeze(1).reshape(1, -1, C), lens, None
+        if self._mask_select():
+            key = (mask.data_ptr(), mask._version, tuple(mask.shape), B)
+            if self._mask_cache is None or self._mask_cache[0] != key:
+                m = mask if mask.shape[0] == B else mask.repeat(B // mask.shape[0], 1)
+                m = m.reshape(B, -1)
+                idx = torch.nonzero(m.reshape(-1) != 0, as_tuple=False).reshape(-1)
+                lens = m.sum(dim=1).tolist()
+                self._mask_cache = (key, idx, [int(v) for v in lens])
+            _, idx, lens = self._mask_cache
+            ysel = y.squeeze(1).reshape(-1, C).index_select(0, idx).reshape(1, -1, C)
+            return ysel, lens, None
+        mask_ = mask if mask.shape[0] == B else mask.repeat([2, 1])
+        lens = [y.shape[2]] * B
+        y = y * mask_.unsqueeze(-1).unsqueeze(1)
+        return y.squeeze(1).reshape(1, -1, C), lens, None
+
+    # ---- forward (stdit.py:238-341) -------------------------------------------------------------
+    def forward(self, x, timestep, y, mask=None):
+        x = x.to(self.dtype)
+        timestep = timestep.to(self.dtype)
+        y = y.to(self.dtype)
+        C = self.hidden_size
+        x = self.x_embedder(x)
+        B = x.shape[0]
+        x = x.reshape(B, self.num_temporal, self.num_spatial, C) + self.pos_embed
+        x = x.reshape(B, self.num_patches, C).contiguous()
+        t = self.t_embedder(timestep, dtype=x.dtype)
+        t0 = self.t_block(t)
+        y = self.y_embedder(y, self.training)
+        y, y_lens, _ = self._select_prompt_tokens(y, mask, C)
+
+        fused = x.is_cuda and x.dtype == torch.float16 and all(b.fused_ok() for b in self.blocks)
+        if fused:
+            x2 = x.reshape(B * self.num_patches, C)
+            y2 = y.reshape(-1, C).contiguous()
+            off = torch.tensor(np.concatenate([[0], np.cumsum(y_lens)]), dtype=torch.int32).to(x.device, non_blocking=True)
+            t0c = t0.contiguous()
+            for i, block in enumerate(self.blocks):
+                block.forward_fused(x2, y2, t0c, off, self.pos_embed_temporal if i == 0 else None, B)
+            x = x2.reshape(B, self.num_patches, C)
+        else:
+            for i, block in enumerate(self.blocks):
+                x = block(x, y, t0, y_lens, self.pos_embed_temporal if i == 0 else None)
+        x = self.final_layer(x, t)
+        x = self.unpatchify(x)
+        return x.to(torch.float32)
+
+    def unpatchify(self, x):
+        N_t, N_h, N_w = [self.input_size[i] // self.patch_size[i] for i in range(3)]
+        T_p, H_p, W_p = self.patch_size
+        B = x.shape[0]
+        x = x.reshape(B, N_t, N_h, N_w, T_p, H_p, W_p, self.out_channels)
+        x = x.permute(0, 7, 1, 4, 2, 5, 3, 6)
+        return x.reshape(B, self.out_channels, N_t * T_p, N_h * H_p, N_w * W_p)
+
+
+def STDiT_XL_2(from_pretrained=None, **kwargs):
+    """STDiT-XL/2 (stdit.py:454-484); checkpoints with fused ``qkv`` rows are split into q/k/v
+    exactly as the reference does (:460-481) when a state dict is loaded via ``load_split_qkv``."""
+    model = STDiT(depth=28, hidden_size=1152, patch_size=(1, 2, 2), num_heads=16, **kwargs)
+    if from_pretrained is not None:
+        load_split_qkv(model, torch.load(from_pretrained, map_location="cpu"))
+    return model
+
+
+def load_split_qkv(model: STDiT, state_dict: dict):
+    """Load an OpenSORA checkpoint, splitting ``*.qkv.{weight,bias}`` rows into q/k/v
+    (stdit.py:460-481, t2v/scripts/split_ckpt.py:3-17)."""
+    sd = {}
+    for k, v in state_dict.items():
+        if k.endswith(".qkv.weight") or k.endswith(".qkv.bias"):
+            base, kind = k.rsplit(".qkv.", 1)
+            for name, part in zip("qkv", v.chunk(3, dim=0)):
+                sd["%s.%s.%s" % (base, name, kind)] = part
+        else:
+            sd[k] = v
+    return model.load_state_dict(sd, strict=False)
