@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py - denoising steps/s of the quantized STDiT 16x512x512 hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched with
+torch.distributed.run, one rank per GPU (RCCL).  Prints ONE JSON line on rank 0.
+
+A "step" = one DDIM iteration for one prompt = 2 STDiT-XL/2 forward-samples (cond + uncond,
+cfg_split as in w8a8_dynamic.yaml) + the fused CFG/DDIM update; inputs (latent, text embeds, packed
+int8 weights) are resident in HBM when the timed region starts.  Multi-GPU: prompts are sharded
+over ranks (weak scaling, one prompt in flight per GPU as the reference's batch_size=1), packed
+weights are broadcast once from rank 0, no collective inside a step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_INT8 = 5.03e15      # dense int8 MFMA ops/s, 256 CU x 2.4 GHz x 8192 op/clk/CU (MI355X_MICROARCH.md / datasheet)
+PEAK_HBM = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--depth", type=int, default=28, help="STDiT depth (28 = STDiT-XL/2; anything else is a debug run)")
+    ap.add_argument("--plan", default="w8a8", choices=["w8a8"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--gemm-variant", type=int, default=None)
+    return ap.parse_args()
+
+
+def cpu_baseline(depth_total=28):
+    """The oracle (CPU restatement of the reference fake-quant path, fp32) timed on this box's host
+    cores on a bounded sample: ONE full-size STDiTBlock forward-sample (x [1,16384,1152], 80 prompt
+    tokens), 2 repeats; steps/s extrapolated as 1 / (t_block * 28 blocks * 2 forward-samples)."""
+    from oracle import stdit_ref as sr
+    torch.manual_seed(0)
+    C, T, S, H = 1152, 16, 1024, 16
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    p = "blocks.0"
+
+    def lin(name, n, k):
+        sd["%s.%s.weight" % (p, name)] = (torch.randn(n, k, generator=g) * (2.0 / (n + k)) ** 0.5).half().float()
+        sd["%s.%s.bias" % (p, name)] = torch.zeros(n)
+    for nm in ("attn.q", "attn.k", "attn.v", "attn.proj", "attn_temp.q", "attn_temp.k", "attn_temp.v", "attn_temp.proj",
+               "cross_attn.q_linear", "cross_attn.proj"):
+        lin(nm, C, C)
+    lin("cross_attn.kv_linear", 2 * C, C)
+    lin("mlp.fc1", 4 * C, C)
+    lin("mlp.fc2", C, 4 * C)
+    sd[p + ".scale_shift_table"] = torch.randn(6, C, generator=g) / C ** 0.5
+    x = torch.randn(1, T * S, C, generator=g).half().float()
+    y = (torch.randn(1, 80, C, generator=g) * 0.3).half().float()
+    t0 = torch.randn(1, 6 * C, generator=g) * 0.1
+    tpe = torch.randn(1, T, C, generator=g) * 0.1
+    spec = sr.QSpec(w_bits=8)
+    times = []
+    with torch.no_grad():
+        for _ in range(2):
+            t_ = time.perf_counter()
+            sr.stdit_block(sd, 0, x, y, t0, [80], tpe, T, S, H, spec)
+            times.append(time.perf_counter() - t_)
+    tb = min(times)
+    return {"value": 1.0 / (tb * depth_total * 2), "unit": "denoising steps/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "1 full-size STDiTBlock forward-sample (16384 tokens x 1152, 80 prompt tokens), fp32 oracle, "
+                      "best of 2 = %.2f s; extrapolated x28 blocks x2 forward-samples per step" % tb}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import viditq_amd  # noqa: F401
+    from viditq_amd import ops, synth, shard
+    from viditq_amd.config import loads_yaml
+    from viditq_amd.t2v import IDDPM
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = loads_yaml(synth.W8A8_DYNAMIC)
+    with torch.no_grad():
+        model = synth.build_stdit(dev, depth=a.depth)
+        qnn = shard.quantize_and_distribute(model, cfg, rank, world)     # rank 0 packs, RCCL broadcast
+        if a.gemm_variant is not None:
+            import functools
+            orig = ops.gemm_i8
+            ops.gemm_i8 = functools.partial(orig, variant=a.gemm_variant)
+        assert all(b.fused_ok() for b in qnn.model.blocks), "hot path must be the fused HIP route"
+        sch = IDDPM(num_sampling_steps=100, cfg_scale=4.0)
+        # one prompt per GPU in flight; prompt index = rank (prompt i -> rank i mod R)
+        embeds, lens = synth.synthetic_prompts(world, dev)
+        x = synth.synthetic_latent(rank, device=dev).float()
+        y = embeds["y"][rank:rank + 1]                                   # [1, 2, 1, 120, 4096]
+        y = y.permute(1, 0, 2, 3, 4).reshape(2, 1, 120, 4096)
+        mask = embeds["mask"][rank:rank + 1]
+        y_c, y_u = y[:1], y[1:]
+        idx = list(range(sch.num_timesteps))[::-1]
+        buf = torch.empty_like(x)
+
+        def step(j, x, buf):
+            i = idx[j % len(idx)]
+            t_id = sch.timestep_map[i]
+            t = torch.full((1,), t_id, device=dev, dtype=torch.long)
+            cond = qnn(x, t, y_c, mask=mask, timestep_id=t_id)
+            unc = qnn(x, t, y_u, mask=mask, timestep_id=t_id)
+            out = sch.ddim_step(x, cond, unc, i, sch.cfg_scale, 0.0, out=buf)
+            return out, x
+
+        for j in range(a.warmup):
+            x, buf = step(j, x, buf)
+        timing = None if a.no_roofline_events else []
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ops.GEMM_TIMING = timing
+        t0 = time.perf_counter()
+        for j in range(a.warmup, a.warmup + a.steps):
+            x, buf = step(j, x, buf)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ops.GEMM_TIMING = None
+        assert torch.isfinite(x).all()
+        status = qnn.check_status()
+
+    el_t = torch.tensor([el], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+    el_max = float(el_t.item())
+
+    roof = None
+    if timing:
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)
+        tot_ops = sum(o for _, _, o, _ in timing)
+        ach = tot_ops / (tot_ms * 1e-3)
+        roof = {"bound": "mfma", "kernel": "gemm_i8_kernel<256,288,128> (W8A8 Linear, int8 MFMA + fused dequant epilogue)",
+                "achieved": ach / 1e12, "peak": PEAK_INT8 / 1e12, "unit": "TFLOP/s", "frac": ach / PEAK_INT8,
+                "traffic": None, "launches": len(timing), "avg_launch_us": tot_ms * 1e3 / len(timing),
+                "gemm_time_share_of_step": tot_ms * 1e-3 / el,
+                "algorithmic_bytes_per_launch_avg": sum(b for _, _, _, b in timing) / len(timing)}
+    if rank == 0:
+        steps_total = a.steps * world
+        value = steps_total / el_max
+        line = {"metric": "denoising steps/sec (whole node), OpenSORA STDiT 16x512x512 W8A8", "value": value,
+                "unit": "denoising steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": el_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "int8 (W8A8 Linear, int32 acc) + fp16 attention/residual",
+                "data": "synthetic (random-init STDiT-XL/2 weights, N(0,1) latents, random text embeds)",
+                "config": {"workload": "OpenSORA STDiT-XL/2 16x512x512 W8A8 (w8a8_dynamic.yaml), 1 prompt per GPU, "
+                                       "DDIM-100 schedule, cfg 4.0, cfg_split, depth %d" % a.depth,
+                           "tokens": 16384, "prompts_in_flight": world, "sharding": "prompt -> rank (no in-step collective)",
+                           "status_word": status},
+                "whole_step_int8_frac": 43.87e12 * (a.depth / 28.0) * value / world / PEAK_INT8,
+                "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

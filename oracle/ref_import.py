@@ -35,6 +35,8 @@ class Cfg(dict):
     """Stand-in for an OmegaConf node: attribute access, .get(), item assignment."""
 
     def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
         try:
             return self[k]
         except KeyError:

@@ -28,3 +28,10 @@ def ops():
     from viditq_amd import _lib
     _lib.load()
     return _ops
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    import torch
+    with torch.no_grad():
+        yield

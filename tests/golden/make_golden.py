@@ -228,6 +228,15 @@ def tiny_stdit(R):
         out["w8a8_uncond"] = qnn(x, t, y[1:], mask=mask)
         # cfg_split False: one B=2 forward (scales shared over cond/uncond)
         out["w8a8_joint"] = qnn(torch.cat([x, x]), torch.cat([t, t]), y, mask=mask)
+        # the reference's own fp16 mode (what it runs on a GPU: model and quant buffers .half()),
+        # on CPU half kernels: the yardstick for "fp16 storage" deviations from the fp32 result
+        import copy
+        q16 = copy.deepcopy(qnn).half()
+        q16.model.dtype = torch.float16
+        out["w8a8_cond_ref_fp16"] = q16(x, t, y[:1].half(), mask=mask).float()
+        q16.set_quant_state(False, False)
+        out["fp_cond_ref_fp16"] = q16(x, t, y[:1].half(), mask=mask).float()
+        del q16
 
         # forward_with_cfg + 3 DDIM steps, driven by the reference's own sampler classes
         from opensora.schedulers.iddpm import IDDPM, forward_with_cfg  # noqa

@@ -108,8 +108,9 @@ def test_smooth_quant_two_ranges_w4_matches_reference(dev, ops):
         layer(x.half().to(dev))
     layer.weight_quantizer.init_done = True
     layer.act_quantizer.init_done = True
-    assert torch.equal(layer.weight_quantizer.delta_list.cpu(), g["sq_delta_list"])
-    assert torch.equal(layer.weight_quantizer.delta.cpu().reshape(-1), g["sq_wdelta"].reshape(-1))
+    # s = act_scale^a / max|W|^(1-a) uses pow(): device and host libm differ in the last ulp
+    assert torch.allclose(layer.weight_quantizer.delta_list.cpu(), g["sq_delta_list"], rtol=1e-5)
+    assert torch.allclose(layer.weight_quantizer.delta.cpu().reshape(-1), g["sq_wdelta"].reshape(-1), rtol=1e-5)
     layer.set_quant_state(True, True)
     for t in (100, 800):
         layer.cur_timestep_id = t
@@ -148,8 +149,10 @@ def test_tiny_stdit_w8a8_fused_path(dev, ops):
     joint = qnn(torch.cat([x, x]), torch.cat([t, t]), y, mask=mask)   # cfg_split False: scales shared over B=2
     assert rel_l2(joint.cpu(), g["w8a8_joint"]) < 5e-3
     assert qnn.check_status() == 0
-    # the yardstick: quantization error itself (vs the FP model) is an order of magnitude larger
-    assert rel_l2(g["w8a8_cond"], g["fp_cond"]) > 5 * rel_l2(cond.cpu(), g["w8a8_cond"])
+    # yardstick: the reference's OWN fp16 mode (model.half(), as it runs on a GPU) deviates from its
+    # fp32 result by fp16-storage rounding + downstream code flips; the HIP path must not be worse
+    ref16_dev = rel_l2(g["w8a8_cond_ref_fp16"], g["w8a8_cond"])
+    assert rel_l2(cond.cpu(), g["w8a8_cond"]) < 1.5 * ref16_dev + 1e-3
 
 
 def test_tiny_stdit_layerwise_equals_fused(dev, ops):

@@ -224,6 +224,11 @@ def pack_weight(W: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, n_bits: 
 
 
 # --------------------------------------------------------------------------- GEMM
+# When set to a list, every GEMM launch is bracketed by two events recorded on the launch stream and
+# (start, end, int8_ops, algorithmic_bytes) is appended - bench.py's live roofline measurement.
+GEMM_TIMING = None
+
+
 def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
             epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
             rows_per_gate: int = 0, variant: int = 0) -> torch.Tensor:
@@ -246,9 +251,18 @@ def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: 
         assert resid.stride(0) == ldo and resid.shape[0] == M
     if gate is not None:
         _req(gate, torch.float32, "gate")
+    timing = GEMM_TIMING
+    if timing is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_L().vq_gemm_i8(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs),
                           _p(bias), _p(out), ldo, _p(resid), _p(gate), rows_per_gate, M, N, a.K, a.Kp,
                           w.n_bits, epilogue, variant, _stream()), "vq_gemm_i8")
+    if timing is not None:
+        e1.record()
+        wbytes = N * a.K // 2 if w.n_bits <= 4 else N * a.K
+        timing.append((e0, e1, 2.0 * M * N * a.K, M * a.K + wbytes + 2 * M * N * (2 if resid is not None else 1)))
     return out
 
 

@@ -274,8 +274,7 @@ class QuantLayer(nn.Module):
                         wq.delta_list = None
                         wq.zero_point_list = None
                 wq.cur_timestep_id = r
-                w_eff = (self.weight.float() * s).to(self.weight.dtype) if s is not None else self.weight
-                weight = wq(w_eff)
+                weight = wq(self.weight, smooth=s)
             else:
                 weight = self.weight_quantizer(self.weight)
             bias = self.bias

@@ -86,20 +86,22 @@ class BaseQuantizer(nn.Module):
         self.delta_list[i_bitwidth, self.cur_timestep_id] = delta
         self.zero_point_list[i_bitwidth, self.cur_timestep_id] = zero_point
 
-    def _params_2d(self, x2d: torch.Tensor, n_bits: int):
-        """min-max (delta, zp) per row of an fp16 [G, E] matrix incl. the global eps fill."""
+    def _params_2d(self, x2d: torch.Tensor, n_bits: int, smooth=None):
+        """min-max (delta, zp) per row of an fp16 [G, E] matrix (times ``smooth`` [E] in fp32) incl. the
+        global eps fill."""
         x2d = x2d.contiguous()
         if x2d.dtype != torch.float16:
             x2d = x2d.half()
         st = ops.new_status(x2d.device)
-        delta, zp = ops.weight_minmax(x2d, n_bits, status=st)
+        delta, zp = ops.weight_minmax(x2d, n_bits, s=smooth, status=st)
         if int(st.item()) & 1:  # init-time host sync only
             self._warn_eps()
-            delta, zp = ops.weight_minmax(x2d, n_bits, force_eps=True)
+            delta, zp = ops.weight_minmax(x2d, n_bits, s=smooth, force_eps=True)
         return delta, zp
 
-    def init_quant_params(self, x: torch.Tensor, per_group=False, momentum=False, n_bits=None):
-        """Min-max init for one bit-width; mirrors base_quantizer.py:146-290."""
+    def init_quant_params(self, x: torch.Tensor, per_group=False, momentum=False, n_bits=None, smooth=None):
+        """Min-max init for one bit-width; mirrors base_quantizer.py:146-290.  ``smooth`` [K] fp32
+        multiplies a 2-D weight in fp32 inside the kernel (W * channel_wise_scale, quant_layer.py:183)."""
         if momentum:
             raise NotImplementedError("running_stat momentum is False in every shipped config")
         i_bitwidth = list(self.mixed_precision).index(n_bits) if (self.mixed_precision is not None and n_bits) else 0
@@ -109,7 +111,7 @@ class BaseQuantizer(nn.Module):
         x = x.detach()
         if per_group == "channel":
             x2d = x.reshape(x.shape[0], -1)
-            delta, zp = self._params_2d(x2d, n_bits)
+            delta, zp = self._params_2d(x2d, n_bits, smooth)
             shape_ = [1] * len(x_shape)
             shape_[0] = x_shape[0]
             delta, zp = delta.reshape(shape_), zp.reshape(shape_)
@@ -146,19 +148,39 @@ class BaseQuantizer(nn.Module):
         out = out.reshape(orig_shape)
         return out if orig_dtype == torch.float16 else out.to(orig_dtype)
 
-    def forward(self, x: torch.Tensor):
+    def forward(self, x: torch.Tensor, smooth=None):
+        if smooth is not None and not (self.per_group == "channel" and x.dim() == 2):
+            raise NotImplementedError("smooth scaling is defined for per-channel Linear weights")
         if self.init_done is not True:
             if self.mixed_precision is not None:
                 for n_bits in self.mixed_precision:
                     assert 2 <= n_bits <= 16, "bitwidth not supported"
-                    self.init_quant_params(x, self.per_group, momentum=self.running_stat, n_bits=n_bits)
+                    self.init_quant_params(x, self.per_group, momentum=self.running_stat, n_bits=n_bits,
+                                           smooth=smooth)
             else:
-                self.init_quant_params(x, self.per_group, momentum=self.running_stat)
+                self.init_quant_params(x, self.per_group, momentum=self.running_stat, smooth=smooth)
             # the reference indexes time-range 0 whatever the current range is (base_quantizer.py:126)
             self.delta = self.delta_list[self.bit_idx, 0]
             self.zero_point = self.zero_point_list[self.bit_idx, 0]
         assert not torch.all(self.delta == -1)
-        return self._fakequant(x)
+        if smooth is None:
+            return self._fakequant(x)
+        return self._fakequant_smoothed_weight(x, smooth)
+
+    def _fakequant_smoothed_weight(self, W: torch.Tensor, smooth: torch.Tensor) -> torch.Tensor:
+        """fake-quant of W*s with the product formed in fp32 in-kernel (pack, then dequantize the
+        codes with torch - calibration-time plumbing, never on the per-step path)."""
+        Wh = (W if W.dtype == torch.float16 else W.half()).contiguous()
+        d, z = self.delta.reshape(-1).float(), self.zero_point.reshape(-1).float()
+        pw = ops.pack_weight(Wh, d, z, self.n_bits, s=smooth.reshape(-1).float().contiguous())
+        K = W.shape[1]
+        if self.n_bits <= 4:
+            b = pw.wq.reshape(W.shape[0], -1, 4).int()
+            codes = torch.cat([b & 0xF, (b >> 4) & 0xF], dim=-1).reshape(W.shape[0], -1)[:, :K].float()
+        else:
+            codes = pw.wq[:, :K].float() + (128.0 if self.n_bits == 8 else 0.0)
+        out = (codes - z[:, None]) * d[:, None]
+        return out.to(W.dtype)
 
     def bitwidth_refactor(self, refactored_bit: int):
         """base_quantizer.py:319-325: changes n_bits / bit_idx, NOT delta."""
