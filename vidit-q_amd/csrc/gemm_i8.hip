@@ -23,6 +23,7 @@
 //
 // Roofline: MFMA-bound (int8 dense peak 5.03 POPS); algorithmic bytes M*K + N*K(/2) + 2*M*N (+2*M*N
 // when a residual is read).
+#include <stdlib.h>
 #include "vq_common.h"
 
 template <int BK>
@@ -52,6 +53,7 @@ struct GemmArgs {
     const half_t* resid;
     const float* gate;
     int ldo, rows_per_gate, M, N, K, Kp, epilogue;
+    int nkt_dbg;  // > 0: run only this many k-tiles (ablation for profiling; results are then wrong)
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool W4>
@@ -239,6 +241,469 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_kernel(GemmArgs
     }
 }
 
+
+// ===========================================================================
+// v2: LDS-DMA (global_load_lds) staged, 16x16x64 MFMA, wave tile 64 tokens x (BN/WAVES_N) channels
+// ===========================================================================
+// Differences to the kernel above (measured motivation: profiles/r01_gemm_pmc.md):
+//   - operands go HBM/L2 -> LDS by global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass that
+//     serialised 8 waves x 9 ds_write_b128 behind the MFMAs every k-tile);
+//   - wave tile 64 x 144 instead of 32 x 288: (WM+WN)/(WM*WN) LDS fragment bytes per MAC drops 35 %;
+//   - v_mfma_i32_16x16x64_i8 so that 144 = 9 x 16 channel tiles; BK = 64 bytes per stage.
+// LDS image: rows of 64 B, 16 rows = one 1 KiB DMA piece (lane i -> row i>>2, slot i&3); the
+// 16-byte chunk c of a row sits in slot c ^ g(row>>2), g = {0,2,3,1}: conflict-free for the
+// ds_read_b128 fragment pattern (lane -> row lane&15, chunk lane>>4).  The DMA destination is
+// lane-linear, so the permutation is applied to the per-lane SOURCE address.
+__device__ __forceinline__ int swz16(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+// BK = 128: rows of 128 B (8 chunks); chunk c sits in slot c ^ ((row>>1)&7) (conflict-free, derivation in DESIGN.md)
+template <int BK>
+__device__ __forceinline__ int swzg(int row) { return BK == 64 ? swz16(row) : ((row >> 1) & 7); }
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_glds_kernel(GemmArgs a) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
+    constexpr int CH = BK / 16;                       // 16-byte chunks per row
+    constexpr int RPP = 64 / CH;                      // rows per 1 KiB DMA piece
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int PIECES = (BM + BN) / RPP;           // 1 KiB DMA pieces per stage
+    constexpr int PPW = (PIECES + NW - 1) / NW;       // pieces per wave
+    static_assert(BM % 16 == 0 && BN % 16 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "16x16 MFMA tiling");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    const int T = MT * NTl;
+    const int bid = blockIdx.x;
+    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // per-lane DMA source offsets (bytes from a.xq / a.wq; loop-invariant except for the k offset)
+    uint32_t soff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + i * NW;
+        const int r = p * RPP + lane / CH;
+        const int c = (lane % CH) ^ swzg<BK>(r);
+        if (r < BM) {
+            int gm = m0 + r;
+            gm = gm < a.M ? gm : a.M - 1;
+            soff[i] = (uint32_t)gm * (uint32_t)a.Kp + c * 16;
+        } else {
+            int gn = n0 + (r - BM);
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)a.Kp + c * 16;
+        }
+    }
+    const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
+    auto issue = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + i * NW;   // wave-uniform: pieces [0, BM/16) hold tokens, the rest weights
+            if (PIECES % NW == 0 || p < PIECES) {
+                const uint8_t* g = (p < BM / RPP ? xbase : a.wq) + soff[i] + kt * BK;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                                 (void __attribute__((address_space(3)))*)(smem + stage * STAGE + p * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    int4v acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
+
+    // fragment read: lane -> row lane&15 of a 16-row tile, 16-byte chunk lane>>4.  Tiles are 1 KiB apart
+    // and (row>>2)&3 does not depend on the tile index (wave/tile row bases are multiples of 16), so one
+    // base offset per operand + compile-time tile offsets address every fragment.
+    const int frow = lane & 15, fc = lane >> 4;
+    int fsw[BK / 64];                                 // per 64-byte k-step: swizzled chunk offset
+#pragma unroll
+    for (int ks = 0; ks < BK / 64; ++ks) fsw[ks] = ((ks * 4 + fc) ^ swzg<BK>(frow)) * 16;
+    const int xfrag = (wm * WTM + frow) * BK;
+    const int wfrag = BM * BK + (wn * WTN + frow) * BK;
+
+    const int nkt = (a.nkt_dbg & 0xffff) > 0 ? (a.nkt_dbg & 0xffff) : a.Kp / BK;
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt && !((a.nkt_dbg & 0x20000) && kt > 0)) issue(cur ^ 1, kt + 1);   // 0x20000: no-DMA ablation
+#pragma unroll
+        for (int ks = 0; ks < BK / 64; ++ks) {
+            const uint8_t* xs = smem + cur * STAGE + xfrag + fsw[ks];
+            const uint8_t* ws = smem + cur * STAGE + wfrag + fsw[ks];
+            int4v xf[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const int4v*>(xs + i * 16 * BK);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int4v wf = *reinterpret_cast<const int4v*>(ws + j * 16 * BK);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    if (!(a.nkt_dbg & 0x40000) || j == 0)   // 0x40000: no-MFMA ablation
+                        acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, xf[i], acc[j][i], 0, 0, 0);
+            }
+            // schedule shape: ALL fragment reads of the k-step first (one exposed LDS latency per k-step
+            // instead of one per 8 MFMAs - profiles/r01_notes.md), then the MFMAs behind counted lgkmcnt waits
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        // pin: without this hipcc sinks most MFMAs BELOW the barrier, i.e. it waits vmcnt(0) for the
+        // DMA it has just issued before doing the math that was meant to hide it
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+
+    if (a.nkt_dbg & 0x10000) {  // ablation: no epilogue (keeps the accumulators live)
+        int x_ = 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) x_ ^= acc[j][i][0] ^ acc[j][i][1] ^ acc[j][i][2] ^ acc[j][i][3];
+        if (x_ == 0x7fffffff) a.out[tid] = (half_t)1.f;
+        return;
+    }
+    // ---- epilogue (same integer form as above; lane = token lane&15, 4 channels per accumulator) ----
+    // Branch-free and register-lean on purpose: per-channel terms are read from LDS once per channel
+    // tile and reused for the 4 token tiles, per-token terms and row pointers live in registers, only
+    // the final store is predicated (a first version with per-(i,j) control flow spilled accumulators
+    // to scratch and cost 16 us per launch - profiles/r01_notes.md).
+    float* l_sw = reinterpret_cast<float*>(smem);
+    int* l_zw = reinterpret_cast<int*>(smem) + BN;
+    int* l_cs = reinterpret_cast<int*>(smem) + 2 * BN;
+    float* l_b = reinterpret_cast<float*>(smem) + 3 * BN;
+    for (int c = tid; c < BN; c += NT) {
+        const int gn = n0 + c;
+        const bool ok = gn < a.N;
+        l_sw[c] = ok ? a.sw[gn] : 0.f;
+        l_zw[c] = ok ? a.zw[gn] : 0;
+        l_cs[c] = ok ? a.cs[gn] : 0;
+        l_b[c] = (ok && a.bias) ? a.bias[gn] : 0.f;
+    }
+    __syncthreads();
+    float sxm[TM];
+    int zxm[TM], Rm[TM];
+    bool mok[TM];
+    half_t* orow[TM];
+    const half_t* rrow[TM];
+    const float* grow[TM];
+    const int ncol0 = n0 + wn * WTN + 4 * fc;      // first channel of this lane in tile j = 0
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + frow;
+        mok[i] = m < a.M;
+        const int mc = mok[i] ? m : a.M - 1;
+        sxm[i] = a.sx[mc];
+        zxm[i] = a.zx[mc];
+        Rm[i] = a.R[mc];
+        orow[i] = a.out + (size_t)mc * a.ldo + ncol0;
+        if constexpr (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID) rrow[i] = a.resid + (size_t)mc * a.ldo + ncol0;
+        if constexpr (EPI == VQ_EPI_GATE_RESID) grow[i] = a.gate + (size_t)(mc / a.rows_per_gate) * a.N + ncol0;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * WTN + j * 16 + 4 * fc;
+        const float4v fsw = *reinterpret_cast<const float4v*>(l_sw + nl);
+        const int4v izw = *reinterpret_cast<const int4v*>(l_zw + nl);
+        const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
+        const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
+        const bool nok = n0 + nl < a.N;               // N % 4 == 0: a quad is all-in or all-out
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tt = acc[j][i][e] - __mul24(izw[e], Rm[i]) - __mul24(zxm[i], ics[e]);
+                y[e] = (sxm[i] * fsw[e]) * (float)tt + fb[e];
+            }
+            const bool ok = nok && mok[i];
+            if constexpr (EPI == VQ_EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f(y[e]);
+            } else if constexpr (EPI == VQ_EPI_GATE_RESID) {
+                half4 rr = {0, 0, 0, 0};
+                float4v g = {0, 0, 0, 0};
+                if (ok) {
+                    rr = *reinterpret_cast<const half4*>(rrow[i] + j * 16);
+                    g = *reinterpret_cast<const float4v*>(grow[i] + j * 16);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (float)rr[e] + g[e] * y[e];
+            } else if constexpr (EPI == VQ_EPI_RESID) {
+                half4 rr = {0, 0, 0, 0};
+                if (ok) rr = *reinterpret_cast<const half4*>(rrow[i] + j * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (float)rr[e] + y[e];
+            }
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)y[e];
+            if (ok) *reinterpret_cast<half4*>(orow[i] + j * 16) = o;
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
+static int launch_gemm_glds_e(const GemmArgs& a, hipStream_t st) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr size_t LDS = 2 * (size_t)(BM + BN) * BK;
+    static_assert(LDS >= 4 * BN * 4, "epilogue parameter staging must fit");
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    auto k = gemm_i8_glds_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LDS);
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3(MT * NTl), dim3(NT), LDS, st, a);
+    return vq_check_launch();
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+static int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
+    switch (a.epilogue) {
+        case VQ_EPI_NONE: return launch_gemm_glds_e<BM, BN, BK, WAVES_M, WAVES_N, VQ_EPI_NONE>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_glds_e<BM, BN, BK, WAVES_M, WAVES_N, VQ_EPI_GELU>(a, st);
+        case VQ_EPI_GATE_RESID: return launch_gemm_glds_e<BM, BN, BK, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID>(a, st);
+        default: return launch_gemm_glds_e<BM, BN, BK, WAVES_M, WAVES_N, VQ_EPI_RESID>(a, st);
+    }
+}
+
+
+// ===========================================================================
+// v3 ("pipe"): 3-stage LDS-DMA ring + register-level fragment prefetch across k-tiles
+// ===========================================================================
+// Ablations of v2 (profiles/r01_notes.md) showed DMA, LDS fragment reads and MFMAs each cost ~0.9 us
+// per 64-byte k-tile and did NOT overlap: the 8 waves of the workgroup run in lockstep between
+// barriers, so "all read LDS", "all issue MFMA" and "all wait for the DMA" were serial phases.
+// Here every wave overlaps them itself:
+//   - fragment reads run TWO 4-MFMA groups ahead (W ring of 3 registers sets) and roll over into the
+//     NEXT k-tile (X fragments double-buffered), so LDS latency sits under the MFMAs;
+//   - ONE barrier per k-tile, placed after MFMA group 6 of 9: by then DMA(kt+1) (issued a full tile
+//     earlier) has landed and every wave has issued its last read of stage kt-1, so the same point
+//     re-issues DMA(kt+2) into that stage; the vmcnt(0) of the barrier only ever waits for a transfer
+//     that had a whole tile of MFMAs to complete.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(GemmArgs a) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
+    constexpr int BK = 64, NSTAGE = 3;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int PIECES = (BM + BN) / 16;
+    constexpr int PPW = (PIECES + NW - 1) / NW;
+    constexpr int BAR_AT = TN >= 4 ? TN - 3 : 0;      // barrier before the reads of group BAR_AT+... roll over
+    static_assert(TM == 4, "X fragment prefetch below is written for 4 token tiles per wave");
+    static_assert(TN >= 3, "W ring of 3");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    const int T = MT * NTl;
+    const int bid = blockIdx.x;
+    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    uint32_t soff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + i * NW;
+        const int r = p * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ swz16(r);
+        if (r < BM) {
+            int gm = m0 + r;
+            gm = gm < a.M ? gm : a.M - 1;
+            soff[i] = (uint32_t)gm * (uint32_t)a.Kp + c * 16;
+        } else {
+            int gn = n0 + (r - BM);
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)a.Kp + c * 16;
+        }
+    }
+    const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
+    auto issue = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + i * NW;
+            if (PIECES % NW == 0 || p < PIECES) {
+                const uint8_t* g = (p < BM / 16 ? xbase : a.wq) + soff[i] + kt * BK;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                                 (void __attribute__((address_space(3)))*)(smem + stage * STAGE + p * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    int4v acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
+
+    const int frow = lane & 15, fc = lane >> 4;
+    const int fsw = (fc ^ swz16(frow)) * 16;
+    const int xfrag = (wm * WTM + frow) * BK + fsw;
+    const int wfrag = BM * BK + (wn * WTN + frow) * BK + fsw;
+    auto ldx = [&](int stage, int i) { return *reinterpret_cast<const int4v*>(smem + stage * STAGE + xfrag + i * 16 * BK); };
+    auto ldw = [&](int stage, int j) { return *reinterpret_cast<const int4v*>(smem + stage * STAGE + wfrag + j * 16 * BK); };
+
+    const int nkt = a.Kp / BK;                        // Kp % 128 == 0  ->  nkt is even and >= 2
+    issue(0, 0);
+    issue(1, 1);
+    __syncthreads();                                  // vmcnt(0): stages 0 and 1 landed
+    int4v xa[TM], xb[TM], w[3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xa[i] = ldx(0, i);
+    w[0] = ldw(0, 0);
+    w[1] = ldw(0, 1);
+
+    // one k-tile: X fragments in X, next tile's go to XN; `cur` / `nxt` / `fill` are LDS stage indices
+#define VQ_PIPE_TILE(X, XN, kt_)                                                                           \
+    {                                                                                                      \
+        const int cur = (kt_) % NSTAGE, nxt = ((kt_) + 1) % NSTAGE, fill = ((kt_) + 2) % NSTAGE;           \
+        const bool more = (kt_) + 1 < nkt;                                                                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+            if (j == BAR_AT) {                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                __syncthreads();                                                                           \
+                if ((kt_) + 2 < nkt) issue(fill, (kt_) + 2);                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (j + 2 < TN) w[(j + 2) % 3] = ldw(cur, j + 2);                                              \
+            else if (more) w[(j + 2) % 3] = ldw(nxt, j + 2 - TN);                                          \
+            if (more && j == TN - 2) { XN[0] = ldx(nxt, 0); XN[1] = ldx(nxt, 1); }                         \
+            if (more && j == TN - 1) { XN[2] = ldx(nxt, 2); XN[3] = ldx(nxt, 3); }                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+                acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[j % 3], X[i], acc[j][i], 0, 0, 0);     \
+            if (j >= TN - 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                            \
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
+        }                                                                                                  \
+    }
+    for (int kt = 0; kt < nkt; kt += 2) {
+        VQ_PIPE_TILE(xa, xb, kt)
+        VQ_PIPE_TILE(xb, xa, kt + 1)
+    }
+#undef VQ_PIPE_TILE
+    __syncthreads();
+
+    // ---- epilogue: identical to the v2 kernel ----
+    float* l_sw = reinterpret_cast<float*>(smem);
+    int* l_zw = reinterpret_cast<int*>(smem) + BN;
+    int* l_cs = reinterpret_cast<int*>(smem) + 2 * BN;
+    float* l_b = reinterpret_cast<float*>(smem) + 3 * BN;
+    for (int c = tid; c < BN; c += NT) {
+        const int gn = n0 + c;
+        const bool ok = gn < a.N;
+        l_sw[c] = ok ? a.sw[gn] : 0.f;
+        l_zw[c] = ok ? a.zw[gn] : 0;
+        l_cs[c] = ok ? a.cs[gn] : 0;
+        l_b[c] = (ok && a.bias) ? a.bias[gn] : 0.f;
+    }
+    __syncthreads();
+    float sxm[TM];
+    int zxm[TM], Rm[TM];
+    bool mok[TM];
+    half_t* orow[TM];
+    const half_t* rrow[TM];
+    const float* grow[TM];
+    const int ncol0 = n0 + wn * WTN + 4 * fc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + frow;
+        mok[i] = m < a.M;
+        const int mc = mok[i] ? m : a.M - 1;
+        sxm[i] = a.sx[mc];
+        zxm[i] = a.zx[mc];
+        Rm[i] = a.R[mc];
+        orow[i] = a.out + (size_t)mc * a.ldo + ncol0;
+        if constexpr (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID) rrow[i] = a.resid + (size_t)mc * a.ldo + ncol0;
+        if constexpr (EPI == VQ_EPI_GATE_RESID) grow[i] = a.gate + (size_t)(mc / a.rows_per_gate) * a.N + ncol0;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * WTN + j * 16 + 4 * fc;
+        const float4v fsw_ = *reinterpret_cast<const float4v*>(l_sw + nl);
+        const int4v izw = *reinterpret_cast<const int4v*>(l_zw + nl);
+        const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
+        const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
+        const bool nok = n0 + nl < a.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tt = acc[j][i][e] - __mul24(izw[e], Rm[i]) - __mul24(zxm[i], ics[e]);
+                y[e] = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
+            }
+            const bool ok = nok && mok[i];
+            if constexpr (EPI == VQ_EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f(y[e]);
+            } else if constexpr (EPI == VQ_EPI_GATE_RESID) {
+                half4 rr = {0, 0, 0, 0};
+                float4v g = {0, 0, 0, 0};
+                if (ok) {
+                    rr = *reinterpret_cast<const half4*>(rrow[i] + j * 16);
+                    g = *reinterpret_cast<const float4v*>(grow[i] + j * 16);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (float)rr[e] + g[e] * y[e];
+            } else if constexpr (EPI == VQ_EPI_RESID) {
+                half4 rr = {0, 0, 0, 0};
+                if (ok) rr = *reinterpret_cast<const half4*>(rrow[i] + j * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (float)rr[e] + y[e];
+            }
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)y[e];
+            if (ok) *reinterpret_cast<half4*>(orow[i] + j * 16) = o;
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+static int launch_gemm_pipe_e(const GemmArgs& a, hipStream_t st) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr size_t LDS = 3 * (size_t)(BM + BN) * 64;
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    auto k = gemm_i8_pipe_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LDS);
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3(MT * NTl), dim3(NT), LDS, st, a);
+    return vq_check_launch();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
+    switch (a.epilogue) {
+        case VQ_EPI_NONE: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU>(a, st);
+        case VQ_EPI_GATE_RESID: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID>(a, st);
+        default: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID>(a, st);
+    }
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 static int launch_gemm(const GemmArgs& a, int w_bits, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -279,7 +744,11 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
     // 24-bit multiplies in the epilogue: |R| < 2^23 needs K <= 2^14
     if (K > 16384) return VQ_ESHAPE;
     GemmArgs a{xq, sx, zx, R, (const uint8_t*)wq, sw, zw, cs, bias, (half_t*)out, (const half_t*)resid, gate,
-               ldo, rows_per_gate > 0 ? rows_per_gate : 1, M, N, K, Kp, epilogue};
+               ldo, rows_per_gate > 0 ? rows_per_gate : 1, M, N, K, Kp, epilogue, 0};
+    {
+        static const char* dbg = getenv("VQ_GEMM_NKT");
+        if (dbg) a.nkt_dbg = atoi(dbg);
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (variant) {
         case 0:  // default: 256 x 288 tile, BK 128, 8 waves along tokens
@@ -290,6 +759,21 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
             return launch_gemm<128, 128, 128, 2, 2>(a, w_bits, st);
         case 3:  // 256 x 256, 8 waves (2x4): wave tile 128 x 64
             return launch_gemm<256, 256, 128, 2, 4>(a, w_bits, st);
+        case 4:  // LDS-DMA staged, 256 x 288, 8 waves (4x2): wave tile 64 x 144 (int8 weights only)
+            if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+            return launch_gemm_glds<256, 288, 64, 4, 2>(a, st);
+        case 5:  // LDS-DMA staged, 256 x 256, wave tile 64 x 128
+            if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+            return launch_gemm_glds<256, 256, 64, 4, 2>(a, st);
+        case 6:  // LDS-DMA staged, 128 x 288, 4 waves (2x2): 2 workgroups per CU
+            if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+            return launch_gemm_glds<128, 288, 64, 2, 2>(a, st);
+        case 7:  // LDS-DMA staged, 256 x 288, BK 128 (full 128-byte lines per row and k-tile)
+            if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+            return launch_gemm_glds<256, 288, 128, 4, 2>(a, st);
+        case 8:  // 3-stage LDS-DMA ring + cross-tile fragment prefetch, 256 x 288
+            if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+            return launch_gemm_pipe<256, 288, 4, 2>(a, st);
         default:
             return VQ_EUNSUP;
     }

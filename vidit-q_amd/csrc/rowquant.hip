@@ -15,6 +15,14 @@
 #define RQ_WAVES 4
 #define RQ_THREADS (RQ_WAVES * 64)
 
+// register-resident hot variants (rowquant_fast.hip); return false when the shape is not covered
+bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, const float* s, int8_t* xq, float* sx,
+                      int32_t* zx, int32_t* R, float* zpf, int n_tok, int C, int Kp, int n_bits, int32_t* status,
+                      hipStream_t st);
+bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float eps, int n_out,
+                 const float* const* s, int8_t* const* xq, float* const* sx, int32_t* const* zx, int32_t* const* R,
+                 half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
+
 __device__ __forceinline__ void store_codes8(int8_t* dst, const int q[8]) {
     uint32_t lo = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) |
                   ((uint32_t)(q[3] & 0xff) << 24);
@@ -339,6 +347,10 @@ extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int a
     if (C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
     if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
     if (add_rows && (add_div <= 0 || n_add <= 0 || (n_tok + add_div - 1) / add_div > n_add)) return VQ_EINVAL;
+    if (B == 1 && !delta_in &&
+        vq_rowquant_fast((const half_t*)x, (const half_t*)add_rows, add_div > 0 ? add_div : 1, s, xq, sx, zx, R, zpf,
+                         n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
+        return vq_check_launch();
     dim3 grid((n_tok + RQ_WAVES - 1) / RQ_WAVES);
     hipLaunchKernelGGL(rowquant_kernel, grid, dim3(RQ_THREADS), 0, (hipStream_t)stream, (const half_t*)x,
                        (const half_t*)add_rows, add_div > 0 ? add_div : 1, s, xq, sx, zx, R, zpf, delta_in, zp_in,
@@ -354,6 +366,11 @@ extern "C" int vq_ln_modulate_rowquant(const void* x, const float* shift, const 
     if (n_out < 1 || n_out > 3 || B <= 0 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
     if (B > LNQ_MAXB || C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
     if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
+    for (int j = 0; j < n_out; ++j)
+        if (!xq[j] || !sx[j] || !zx[j] || !R[j]) return VQ_EINVAL;
+    if (B == 1 && vq_lnq_fast((const half_t*)x, shift, scale, ln_eps, n_out, s, xq, sx, zx, R, (half_t*)xm_out, n_tok,
+                              C, Kp, n_bits, status, (hipStream_t)stream))
+        return vq_check_launch();
     LnqOut o;
     for (int j = 0; j < 3; ++j) {
         const bool on = j < n_out;

@@ -227,11 +227,14 @@ def pack_weight(W: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, n_bits: 
 # When set to a list, every GEMM launch is bracketed by two events recorded on the launch stream and
 # (start, end, int8_ops, algorithmic_bytes) is appended - bench.py's live roofline measurement.
 GEMM_TIMING = None
+# kernel variant used when the caller does not choose: 4 = LDS-DMA staged 256x288 tile (csrc/gemm_i8.hip);
+# nibble-packed (<= 4 bit) weights are routed to the register-staged kernel by the library
+DEFAULT_GEMM_VARIANT = 4
 
 
 def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
             epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
-            rows_per_gate: int = 0, variant: int = 0) -> torch.Tensor:
+            rows_per_gate: int = 0, variant: int = -1) -> torch.Tensor:
     """out[M, N] fp16 = dequant(int8 MFMA(a, w)) + bias, with the fused epilogue."""
     if a.K != w.K or a.Kp != w.Kp:
         raise VQError("K mismatch: activation %d/%d weight %d/%d" % (a.K, a.Kp, w.K, w.Kp))
@@ -251,6 +254,8 @@ def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: 
         assert resid.stride(0) == ldo and resid.shape[0] == M
     if gate is not None:
         _req(gate, torch.float32, "gate")
+    if variant < 0:
+        variant = DEFAULT_GEMM_VARIANT
     timing = GEMM_TIMING
     if timing is not None:
         e0 = torch.cuda.Event(enable_timing=True)
