@@ -1,0 +1,154 @@
+"""CPU tests of the host-side mirror of the reference API (no kernels are launched)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz, quant_params_of
+
+REF = "/root/reference"
+
+
+def _cfgs(**kw):
+    import viditq_amd  # noqa
+    from viditq_amd import synth
+    from viditq_amd.config import loads_yaml
+    return synth.quant_params_from_config(loads_yaml(synth.W8A8_DYNAMIC), T=4, S=16, n_prompt=12)
+
+
+def _tiny_qnn():
+    import viditq_amd  # noqa
+    from viditq_amd.qdiff.models import QuantModel
+    from viditq_amd.t2v import STDiT
+    torch.manual_seed(0)
+    m = STDiT(input_size=(4, 8, 8), depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
+    wq, aq = _cfgs()
+    qnn = QuantModel(m, wq, aq)
+    qnn.set_module_name_for_quantizer(qnn.model)
+    return qnn
+
+
+def test_config_node_semantics_match_omegaconf_usage():
+    from viditq_amd.config import ListConfig, QuantConfig, loads_yaml
+    from viditq_amd import synth
+    cfg = loads_yaml(synth.W8A8_DYNAMIC)
+    assert cfg.quant.weight.quantizer.n_bits == 8 and cfg.quant.activation.quantizer.get("dynamic") is True
+    assert cfg.get("nope") is None and cfg.nope is None                 # .get() / attribute on missing keys
+    assert isinstance(cfg.mixed_precision, ListConfig) and list(cfg.mixed_precision) == [4, 6, 8]
+    wq = cfg.quant.weight.quantizer
+    wq["mixed_precision"] = cfg.mixed_precision                         # item assignment (quant_txt2video.py:137)
+    assert wq.mixed_precision.index(8) == 2
+    assert isinstance(cfg.quant.activation.quantizer.smooth_quant, QuantConfig)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+@pytest.mark.parametrize("name", ["w8a8_dynamic.yaml", "w4a8_timestep_aware_cb.yaml", "w8a8_naive.yaml",
+                                  "w6a6_naive_cb.yaml", "w4a8_naive_cb.yaml"])
+def test_reference_ptq_yamls_drop_in_unchanged(name):
+    """The reference's own PTQ YAMLs load and build the quantized module tree without edits."""
+    import viditq_amd  # noqa
+    from viditq_amd import synth
+    from viditq_amd.config import load_yaml
+    from viditq_amd.qdiff.models import QuantLayer, QuantModel
+    from viditq_amd.t2v import STDiT
+    cfg = load_yaml(os.path.join(REF, "t2v/configs/quant/opensora", name))
+    wq, aq = synth.quant_params_from_config(cfg)
+    m = STDiT(input_size=(4, 8, 8), depth=1, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
+    qnn = QuantModel(m, wq, aq)
+    layers = [l for _, l in qnn.quant_layers()]
+    assert len(layers) == 13 + 6
+    assert layers[0].weight_quantizer.n_bits == cfg.quant.weight.quantizer.n_bits
+    sq = cfg.quant.activation.quantizer.get("smooth_quant") or {}
+    assert all(bool(l.smooth_quant) == bool(sq.get("enable", False)) for l in layers)
+    fp_list = open(os.path.join(REF, "t2v/configs/quant/opensora/remain_fp.txt")).read().split()
+    assert fp_list == synth.REMAIN_FP
+
+
+def test_pattern_in_matches_reference_semantics():
+    from viditq_amd.qdiff.models import pattern_in
+    cases = [("model.blocks.3.attn.q", "blocks.3.attn.q", True), ("model.blocks.13.attn.q", "blocks.3", False),
+             ("model.blocks.5.mlp.fc1", "blocks.[0-6].mlp", True), ("model.blocks.7.mlp.fc1", "blocks.[0-6].mlp", False),
+             ("model.blocks.2.cross_attn.proj", "blocks.*.cross_attn", True), ("model.x_embedder.proj", "x_embedder", True),
+             ("model.t_embedder.mlp.0", "embedder", False), ("model.final_layer.linear", "final_layer", True)]
+    for text, pat, want in cases:
+        assert pattern_in(text, pat) is want, (text, pat)
+    if os.path.isdir(REF):
+        from oracle import ref_import
+        R = ref_import.load()
+        for text, pat, _ in cases:
+            assert R.pattern_in(text, pat) == pattern_in(text, pat)
+
+
+def test_quant_model_name_routing_and_state_api():
+    from viditq_amd.qdiff import models as qm
+    qnn = _tiny_qnn()
+    named = dict(qnn.quant_layers())
+    assert len(named) == 2 * 13 + 6                                      # 13 per block + 6 FP-mode wrappers
+    assert type(named["blocks.0.attn.q"]) is qm.QuantSpatialAttnLinear
+    assert type(named["blocks.1.attn_temp.proj"]) is qm.QuantTemporalAttnLinear
+    assert type(named["blocks.0.cross_attn.kv_linear"]) is qm.QuantCrossAttnLinear
+    assert type(named["blocks.1.mlp.fc2"]) is qm.QuantLayer
+    assert type(named["final_layer.linear"]) is qm.QuantLayer and type(named["t_block.1"]) is qm.QuantLayer
+    assert not isinstance(qnn.model.x_embedder.proj, qm.QuantLayer)      # Conv3d is not wrapped (quant_model.py:73)
+    # aliasing, not copying, of the original parameters (quant_layer.py:46-56)
+    l = named["blocks.0.mlp.fc1"]
+    assert l.weight is l.org_module.weight and l.org_weight is l.weight
+    qnn.fp_layer_list = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+    qnn.set_quant_state(True, True)
+    states = {n: l.get_quant_state() for n, l in named.items()}
+    assert all(v == (True, True) for n, v in states.items() if n.startswith("blocks"))
+    assert all(v == (False, False) for n, v in states.items() if not n.startswith("blocks"))
+    qnn.set_layer_quant(model=qnn, module_name_list=["blocks.1.mlp"], quant_level="per_layer", weight_quant=False,
+                        act_quant=False, prefix="")
+    assert named["blocks.1.mlp.fc1"].get_quant_state() == (False, False)
+    assert named["blocks.0.mlp.fc1"].get_quant_state() == (True, True)
+    qnn.load_bitwidth_config(qnn, {"model.blocks.0.mlp.fc1": 4}, "weight")
+    assert named["blocks.0.mlp.fc1"].weight_quantizer.n_bits == 4 and named["blocks.0.mlp.fc1"].weight_quantizer.bit_idx == 0
+    assert named["blocks.0.mlp.fc2"].weight_quantizer.n_bits == 8
+    assert qnn.in_channels == 4 and qnn.hidden_size == 64                # attribute fall-through (quant_model.py:589)
+    qnn.set_quant_init_done("weight")
+    assert all(l.weight_quantizer.init_done and not l.act_quantizer.init_done for l in named.values())
+
+
+def test_ckpt_schema_roundtrip_from_reference_golden():
+    """get/set_quant_params_dict speak the reference's ckpt.pth schema (quant_model.py:220-269)."""
+    from viditq_amd.qdiff.quantizer import BaseQuantizer
+    g = load_npz("tiny_stdit_w8a8.npz")
+    qnn = _tiny_qnn()
+    qp = quant_params_of(g)
+    full = {}
+    for mod in qnn.model.modules():
+        if isinstance(mod, BaseQuantizer):
+            full[mod.module_name] = [qp.get(mod.module_name, {}), {}]
+    assert len(full) == 2 * 32                                            # a weight + an act quantizer per layer
+    qnn.set_quant_params_dict(full)
+    out = qnn.get_quant_params_dict()
+    assert set(out) == set(full)
+    wq = qnn.model.blocks[0].attn.q.weight_quantizer
+    assert torch.equal(wq.delta, qp["blocks.0.attn.q.weight_quantizer"]["delta"])
+    assert wq.delta_list.shape == (1, 1, 64, 1)
+    assert list(out["blocks.0.attn.q.weight_quantizer"][0]) == ["delta_list", "zero_point_list", "delta", "zero_point", "alpha"]
+
+
+def test_iddpm_schedule_and_cfg_rule_cpu():
+    from viditq_amd.t2v import IDDPM, forward_with_cfg, space_timesteps
+    g = load_npz("tiny_stdit_w8a8.npz")
+    s = IDDPM(num_sampling_steps=100)
+    assert s.timestep_map == [int(v) for v in g["tmap100"]] and np.allclose(s.alphas_cumprod, g["acp100"], rtol=1e-14)
+    assert sorted(space_timesteps(1000, "100")) == s.timestep_map
+    assert len(space_timesteps(1000, "ddim50")) == 50
+
+    class Fake(torch.nn.Module):                                           # stands in for the model: out = f(x, y)
+        cfg_split = True
+
+        def forward(self, x, t, y, **kw):
+            return torch.cat([x * y.reshape(-1, 1, 1, 1, 1)[:, :1], x + 1], dim=1)
+    x = torch.randn(2, 4, 2, 2, 2)
+    xx = torch.cat([x[:1], x[:1]])
+    y = torch.tensor([2.0, -1.0])
+    out = forward_with_cfg(Fake(), xx, torch.tensor([721, 721]), y, 4.0)
+    cond, unc = Fake().forward(x[:1], None, y[:1]), Fake().forward(x[:1], None, y[1:])
+    half = unc[:, :3] + 4.0 * (cond[:, :3] - unc[:, :3])                   # guidance on 3 of 4 eps channels (A.4-5)
+    assert torch.allclose(out[:1, :3], half) and torch.allclose(out[1:, :3], half)
+    assert torch.equal(out[:1, 3:], cond[:, 3:]) and torch.equal(out[1:, 3:], unc[:, 3:])
