@@ -180,6 +180,10 @@ int vq_cfg_ddim_step(const float* cond, const float* uncond, const float* x, flo
  * out[32*32] int32 with A(32x32,i8) * B^T using one wave; a,b are [32,32] int8. */
 int vq_probe_mfma_i8(const int8_t* a, const int8_t* b, int32_t* out, void* stream);
 
+/* MFMA / LDS / barrier issue-rate micro-benchmark (library self-test, tools/mfma_rate.py). */
+int vq_probe_mfma_rate(int mode, int iters, int blocks, int* out, void* stream);
+int vq_probe_stage_rate(int mode, const void* src, int stride, int iters, int blocks, int* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,7 +138,7 @@ def _oracle_linear(x, W, b, w_bits, a_bits, s=None):
                            smooth=None if s is None else s.reshape(1, -1))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("M,N,K", [(64, 48, 96), (300, 292, 128), (512, 576, 1152), (130, 1152, 4608)])
 def test_gemm_w8a8_vs_oracle(ops, dev, variant, M, N, K):
     x = h16(1, M, K, scale=1.5, seed=M + K)
@@ -180,7 +180,7 @@ def test_gemm_epilogues(ops, dev):
     qa = ops.rowquant(x.to(dev))
     d, z = ops.weight_minmax(W.to(dev), 8)
     pw = ops.pack_weight(W.to(dev), d, z, 8)
-    for variant in (0, 4, 8):
+    for variant in (0, 4, 8, 9, 10):
         out = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=ops.EPI_GELU, variant=variant).cpu().float()
         assert rel_l2(out, fq.gelu_tanh(y)) < 5e-4
         out = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=ops.EPI_RESID, resid=resid.to(dev), variant=variant)

@@ -34,6 +34,8 @@ SIGNATURES = {
     "vq_attn_temporal": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _f, _vp]),
     "vq_adaln_table": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "vq_probe_mfma_i8": (_i, [_vp, _vp, _vp, _vp]),
+    "vq_probe_stage_rate": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
+    "vq_probe_mfma_rate": (_i, [_i, _i, _i, _vp, _vp]),
     "vq_cfg_ddim_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
 }
 

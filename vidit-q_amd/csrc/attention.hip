@@ -380,8 +380,8 @@ template <int D>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
     using C = AttCfg<D>;
     auto k = attn_fwd_kernel<D>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       C::LDS);
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);  // once
     if (e != hipSuccess) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
@@ -416,8 +416,8 @@ template <int D>
 static int launch_temporal(const TempArgs& a, hipStream_t st) {
     constexpr int LDS = 3 * 32 * (4 * D * 2 + 16);
     auto k = attn_temporal_kernel<D>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       LDS);
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);  // once
     if (e != hipSuccess) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;

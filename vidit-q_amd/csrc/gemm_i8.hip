@@ -459,8 +459,8 @@ static int launch_gemm_glds_e(const GemmArgs& a, hipStream_t st) {
     static_assert(LDS >= 4 * BN * 4, "epilogue parameter staging must fit");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
     auto k = gemm_i8_glds_kernel<BM, BN, BK, WAVES_M, WAVES_N, EPI>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS);
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
     if (e != hipSuccess) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
@@ -493,18 +493,27 @@ static int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
 //     earlier) has landed and every wave has issued its last read of stage kt-1, so the same point
 //     re-issues DMA(kt+2) into that stage; the vmcnt(0) of the barrier only ever waits for a transfer
 //     that had a whole tile of MFMAs to complete.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(GemmArgs a) {
+    // NSTAGE == 3: one DMA batch in flight (plain __syncthreads, vmcnt(0)).
+    // NSTAGE == 4: TWO batches in flight: the mid-tile wait is a COUNTED s_waitcnt vmcnt(P) (P = this
+    //              wave's pieces per batch) + raw s_barrier, so DMA(kt+2) keeps flying while DMA(kt+1) is
+    //              consumed and DMA(kt+3) is issued - the k-tile batch latency (~1800 cycles, measured)
+    //              is then amortised over two tiles.
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
-    constexpr int BK = 64, NSTAGE = 3;
+    constexpr int BK = 64;
+    constexpr int AHEAD = NSTAGE - 1;                 // DMA distance in k-tiles
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int STAGE = (BM + BN) * BK;
     constexpr int PIECES = (BM + BN) / 16;
     constexpr int PPW = (PIECES + NW - 1) / NW;
-    constexpr int BAR_AT = TN >= 4 ? TN - 3 : 0;      // barrier before the reads of group BAR_AT+... roll over
+    constexpr int PLAST = PIECES - (PPW - 1) * NW;    // waves < PLAST issue PPW pieces, the others PPW-1
+    constexpr int BAR_AT = TN >= 4 ? TN - 3 : 0;
+    constexpr int BAR_B = TN >= 6 ? 2 : 0;            // barrier position of the staggered half
     static_assert(TM == 4, "X fragment prefetch below is written for 4 token tiles per wave");
     static_assert(TN >= 3, "W ring of 3");
+    static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -518,6 +527,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const bool full_wave = (PIECES % NW == 0) || wave < PLAST;   // wave-uniform: issues PPW pieces per batch
 
     uint32_t soff[PPW];
 #pragma unroll
@@ -548,6 +558,22 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
             }
         }
     };
+    // wait until at most `batches` of this wave's DMA batches are outstanding, then workgroup barrier
+    auto wait_and_barrier = [&](int batches) {
+        if constexpr (NSTAGE == 3) {
+            __syncthreads();
+        } else {
+            if (batches == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (batches == 1) {
+                if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
+            } else {
+                if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * (PPW - 1)) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    };
 
     int4v acc[TN][TM];
 #pragma unroll
@@ -565,25 +591,31 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
     const int nkt = a.Kp / BK;                        // Kp % 128 == 0  ->  nkt is even and >= 2
     issue(0, 0);
     issue(1, 1);
-    __syncthreads();                                  // vmcnt(0): stages 0 and 1 landed
+    if (NSTAGE == 4 && nkt > 2) issue(2, 2);
+    wait_and_barrier(NSTAGE == 4 ? (nkt > 2 ? 2 : 1) : 0);   // stage 0 landed (NSTAGE 3: stages 0 and 1)
     int4v xa[TM], xb[TM], w[3];
 #pragma unroll
     for (int i = 0; i < TM; ++i) xa[i] = ldx(0, i);
     w[0] = ldw(0, 0);
     w[1] = ldw(0, 1);
 
-    // one k-tile: X fragments in X, next tile's go to XN; `cur` / `nxt` / `fill` are LDS stage indices
-#define VQ_PIPE_TILE(X, XN, kt_)                                                                           \
+#define VQ_PIPE_TILE(X, XN, kt_, BARJ, DMAJ)                                                               \
     {                                                                                                      \
-        const int cur = (kt_) % NSTAGE, nxt = ((kt_) + 1) % NSTAGE, fill = ((kt_) + 2) % NSTAGE;           \
+        const int cur = (kt_) % NSTAGE, nxt = ((kt_) + 1) % NSTAGE, fill = ((kt_) + AHEAD) % NSTAGE;       \
         const bool more = (kt_) + 1 < nkt;                                                                 \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
-            if (j == BAR_AT) {                                                                             \
+            if (j == BARJ) {                                                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
-                __syncthreads();                                                                           \
-                if ((kt_) + 2 < nkt) issue(fill, (kt_) + 2);                                               \
+                /* DMA(kt+1) must have landed; with 4 stages DMA(kt+2) may stay in flight */               \
+                wait_and_barrier((NSTAGE == 4 && (kt_) + 2 < nkt) ? 1 : 0);                                \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
             }                                                                                              \
+            if (j == DMAJ) {                                                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                if ((kt_) + AHEAD < nkt) issue(fill, (kt_) + AHEAD);                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            /* fragment prefetch two groups ahead; reads of the NEXT stage only after this tile's barrier */ \
             if (j + 2 < TN) w[(j + 2) % 3] = ldw(cur, j + 2);                                              \
             else if (more) w[(j + 2) % 3] = ldw(nxt, j + 2 - TN);                                          \
             if (more && j == TN - 2) { XN[0] = ldx(nxt, 0); XN[1] = ldx(nxt, 1); }                         \
@@ -595,18 +627,36 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
         }                                                                                                  \
     }
-    for (int kt = 0; kt < nkt; kt += 2) {
-        VQ_PIPE_TILE(xa, xb, kt)
-        VQ_PIPE_TILE(xb, xa, kt + 1)
+    if (!STAGGER || wave < NW / 2) {
+        for (int kt = 0; kt < nkt; kt += 2) {
+            VQ_PIPE_TILE(xa, xb, kt, BAR_AT, BAR_AT)
+            VQ_PIPE_TILE(xb, xa, kt + 1, BAR_AT, BAR_AT)
+        }
+    } else {
+        // second half of the waves (the SIMD partners of waves 0..NW/2-1): same barrier count per k-tile,
+        // but barrier early and DMA issue late, so that one partner issues its LDS-DMA pieces (which block
+        // the issuing wave for ~100+ cycles each) while the other one owns the MFMA pipe
+        for (int kt = 0; kt < nkt; kt += 2) {
+            VQ_PIPE_TILE(xa, xb, kt, BAR_B, BAR_AT)
+            VQ_PIPE_TILE(xb, xa, kt + 1, BAR_B, BAR_AT)
+        }
     }
 #undef VQ_PIPE_TILE
     __syncthreads();
 
-    // ---- epilogue: identical to the v2 kernel ----
-    float* l_sw = reinterpret_cast<float*>(smem);
-    int* l_zw = reinterpret_cast<int*>(smem) + BN;
-    int* l_cs = reinterpret_cast<int*>(smem) + 2 * BN;
-    float* l_b = reinterpret_cast<float*>(smem) + 3 * BN;
+    // ---- epilogue: dequantise in the MFMA layout, transpose through LDS, store whole row runs ----
+    // The v2 epilogue stored 8 bytes per lane (16 rows x 32 B per instruction) and reached 2.9 TB/s of
+    // output; a plain fill of the same buffer runs at 5-6.4 TB/s (tools/write_bw.py).  Here every wave
+    // parks its 64 x WTN fp16 sub-tile in its own LDS slab (row stride ROWB), then re-reads it as 16-byte
+    // chunks in row-major order, so one store instruction covers contiguous WTN*2-byte runs of ~3.5 rows;
+    // the residual / gate operands of the fused adds are read with the same coalesced pattern.
+    constexpr int ROWB = WTN * 2 + 16;                // slab row stride in bytes (16 B aligned; 2-way write conflicts)
+    constexpr int SLAB = WTM * ROWB;
+    constexpr int PAR_OFF = NW * SLAB;                // per-channel parameter block behind the slabs
+    float* l_sw = reinterpret_cast<float*>(smem + PAR_OFF);
+    int* l_zw = reinterpret_cast<int*>(smem + PAR_OFF) + BN;
+    int* l_cs = reinterpret_cast<int*>(smem + PAR_OFF) + 2 * BN;
+    float* l_b = reinterpret_cast<float*>(smem + PAR_OFF) + 3 * BN;
     for (int c = tid; c < BN; c += NT) {
         const int gn = n0 + c;
         const bool ok = gn < a.N;
@@ -616,76 +666,91 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
         l_b[c] = (ok && a.bias) ? a.bias[gn] : 0.f;
     }
     __syncthreads();
-    float sxm[TM];
-    int zxm[TM], Rm[TM];
-    bool mok[TM];
-    half_t* orow[TM];
-    const half_t* rrow[TM];
-    const float* grow[TM];
-    const int ncol0 = n0 + wn * WTN + 4 * fc;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + frow;
-        mok[i] = m < a.M;
-        const int mc = mok[i] ? m : a.M - 1;
-        sxm[i] = a.sx[mc];
-        zxm[i] = a.zx[mc];
-        Rm[i] = a.R[mc];
-        orow[i] = a.out + (size_t)mc * a.ldo + ncol0;
-        if constexpr (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID) rrow[i] = a.resid + (size_t)mc * a.ldo + ncol0;
-        if constexpr (EPI == VQ_EPI_GATE_RESID) grow[i] = a.gate + (size_t)(mc / a.rows_per_gate) * a.N + ncol0;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nl = wn * WTN + j * 16 + 4 * fc;
-        const float4v fsw_ = *reinterpret_cast<const float4v*>(l_sw + nl);
-        const int4v izw = *reinterpret_cast<const int4v*>(l_zw + nl);
-        const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
-        const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
-        const bool nok = n0 + nl < a.N;
+    uint8_t* slab = smem + wave * SLAB;
+    {
+        float sxm[TM];
+        int zxm[TM], Rm[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float y[4];
+            const int m = m0 + wm * WTM + i * 16 + frow;
+            const int mc = m < a.M ? m : a.M - 1;
+            sxm[i] = a.sx[mc];
+            zxm[i] = a.zx[mc];
+            Rm[i] = a.R[mc];
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int tt = acc[j][i][e] - __mul24(izw[e], Rm[i]) - __mul24(zxm[i], ics[e]);
-                y[e] = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
-            }
-            const bool ok = nok && mok[i];
-            if constexpr (EPI == VQ_EPI_GELU) {
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * WTN + j * 16 + 4 * fc;
+            const float4v fsw_ = *reinterpret_cast<const float4v*>(l_sw + nl);
+            const int4v izw = *reinterpret_cast<const int4v*>(l_zw + nl);
+            const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
+            const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f(y[e]);
-            } else if constexpr (EPI == VQ_EPI_GATE_RESID) {
-                half4 rr = {0, 0, 0, 0};
-                float4v g = {0, 0, 0, 0};
-                if (ok) {
-                    rr = *reinterpret_cast<const half4*>(rrow[i] + j * 16);
-                    g = *reinterpret_cast<const float4v*>(grow[i] + j * 16);
+            for (int i = 0; i < TM; ++i) {
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tt = acc[j][i][e] - __mul24(izw[e], Rm[i]) - __mul24(zxm[i], ics[e]);
+                    float y = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
+                    if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
+                    o[e] = (half_t)y;
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (float)rr[e] + g[e] * y[e];
-            } else if constexpr (EPI == VQ_EPI_RESID) {
-                half4 rr = {0, 0, 0, 0};
-                if (ok) rr = *reinterpret_cast<const half4*>(rrow[i] + j * 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (float)rr[e] + y[e];
+                *reinterpret_cast<half4*>(slab + (i * 16 + frow) * ROWB + (j * 16 + 4 * fc) * 2) = o;
             }
-            half4 o;
+        }
+    }
+    // second pass: this wave's slab, row-major 16-byte chunks (same wave wrote it: LDS ops are in order)
+    constexpr int CPR = WTN / 8;                      // 16-byte chunks per slab row
+    constexpr int NCH = WTM * CPR;
+    const int mrow0 = m0 + wm * WTM, ncol0 = n0 + wn * WTN;
+#pragma unroll 2
+    for (int c = lane; c < NCH; c += 64) {
+        const int row = c / CPR, col = (c % CPR) * 8;
+        const int m = mrow0 + row, n = ncol0 + col;
+        if (m >= a.M || n >= a.N) continue;
+        half8 y = *reinterpret_cast<const half8*>(slab + row * ROWB + col * 2);
+        const size_t off = (size_t)m * a.ldo + n;
+        const bool full = n + 8 <= a.N;               // N % 4 == 0: otherwise exactly 4 valid
+        if constexpr (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID) {
+            half8 rr;
+            if (full) rr = *reinterpret_cast<const half8*>(a.resid + off);
+            else {
+                const half4 r4 = *reinterpret_cast<const half4*>(a.resid + off);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (half_t)y[e];
-            if (ok) *reinterpret_cast<half4*>(orow[i] + j * 16) = o;
+                for (int e = 0; e < 4; ++e) { rr[e] = r4[e]; rr[4 + e] = (half_t)0.f; }
+            }
+            if constexpr (EPI == VQ_EPI_GATE_RESID) {
+                const float* g = a.gate + (size_t)(m / a.rows_per_gate) * a.N + n;
+                const float4v g0 = *reinterpret_cast<const float4v*>(g);
+                const float4v g1 = full ? *reinterpret_cast<const float4v*>(g + 4) : float4v{0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)rr[e] + (e < 4 ? g0[e] : g1[e - 4]) * (float)y[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)rr[e] + (float)y[e]);
+            }
+        }
+        if (full) *reinterpret_cast<half8*>(a.out + off) = y;
+        else {
+            half4 y4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y4[e] = y[e];
+            *reinterpret_cast<half4*>(a.out + off) = y4;
         }
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER>
 static int launch_gemm_pipe_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
-    constexpr size_t LDS = 3 * (size_t)(BM + BN) * 64;
+    constexpr size_t RING = NSTAGE * (size_t)(BM + BN) * 64;
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4;
+    constexpr size_t LDS = RING > EPIL ? RING : EPIL;
+    static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    auto k = gemm_i8_pipe_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS);
+    auto k = gemm_i8_pipe_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, STAGGER>;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
     if (e != hipSuccess) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
@@ -694,13 +759,14 @@ static int launch_gemm_pipe_e(const GemmArgs& a, hipStream_t st) {
     return vq_check_launch();
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool STAGGER>
 static int launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
     switch (a.epilogue) {
-        case VQ_EPI_NONE: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE>(a, st);
-        case VQ_EPI_GELU: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU>(a, st);
-        case VQ_EPI_GATE_RESID: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID>(a, st);
-        default: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID>(a, st);
+        case VQ_EPI_NONE: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, NSTAGE, STAGGER>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, NSTAGE, STAGGER>(a, st);
+        case VQ_EPI_GATE_RESID:
+            return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, NSTAGE, STAGGER>(a, st);
+        default: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, NSTAGE, STAGGER>(a, st);
     }
 }
 
@@ -714,13 +780,15 @@ static int launch_gemm(const GemmArgs& a, int w_bits, hipStream_t st) {
     hipError_t e;
     if (w_bits <= 4) {
         auto k = gemm_i8_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)LDS);
+        static hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
+        e = e4;
         if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, LDS, st, a);
     } else {
         auto k = gemm_i8_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)LDS);
+        static hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
+        e = e8;
         if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, LDS, st, a);
     }
     if (e != hipSuccess) {
@@ -773,7 +841,13 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
             return launch_gemm_glds<256, 288, 128, 4, 2>(a, st);
         case 8:  // 3-stage LDS-DMA ring + cross-tile fragment prefetch, 256 x 288
             if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
-            return launch_gemm_pipe<256, 288, 4, 2>(a, st);
+            return launch_gemm_pipe<256, 288, 4, 2, 3, false>(a, st);
+        case 9:  // 4-stage ring, two DMA batches in flight (counted vmcnt + raw s_barrier)
+            if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+            return launch_gemm_pipe<256, 288, 4, 2, 4, false>(a, st);
+        case 10:  // 4-stage ring + staggered wave halves (DMA issue of one half under the MFMAs of the other)
+            if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+            return launch_gemm_pipe<256, 288, 4, 2, 4, true>(a, st);
         default:
             return VQ_EUNSUP;
     }

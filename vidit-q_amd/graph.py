@@ -1,0 +1,75 @@
+"""HIP-graph capture of the per-step forwards.
+
+One denoising step launches ~2300 kernels from Python (28 blocks x ~20 kernels x 2 forward-samples);
+at ~64 ms of GPU work per step the eager loop is partly host-bound.  Shapes, buffers and the kernel
+sequence are static within a smooth-quant time-range, so both forward-samples of a step (cond +
+uncond) are captured ONCE into a HIP graph (``torch.cuda.CUDAGraph`` records the raw
+``hipLaunchKernelGGL`` calls our C ABI makes on the capturing stream) and replayed with new latent /
+timestep / text-embedding contents copied into the static input buffers.  One graph per time-range
+(the packed weights and smoothing vectors differ between ranges).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+
+class StepGraph:
+    """cond/uncond forwards of a QuantModel for one prompt as a replayable HIP graph."""
+
+    def __init__(self, qnn, x: torch.Tensor, y_cond: torch.Tensor, y_uncond: torch.Tensor,
+                 mask: Optional[torch.Tensor], timestep_id: int, warmup: int = 2):
+        self.qnn = qnn
+        self.x = x.clone()
+        self.t = torch.full((x.shape[0],), int(timestep_id), device=x.device, dtype=torch.long)
+        self.yc, self.yu = y_cond.clone(), y_uncond.clone()
+        self.mask = mask
+        self.cfg_split = bool(getattr(qnn, "cfg_split", False))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                      # warm caches (mask select, packed weights, MIOpen find)
+                self._forward(timestep_id)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.cond, self.uncond = self._forward(timestep_id)
+
+    def _forward(self, t_id):
+        q = self.qnn
+        if self.cfg_split:
+            return (q(self.x, self.t, self.yc, mask=self.mask, timestep_id=t_id),
+                    q(self.x, self.t, self.yu, mask=self.mask, timestep_id=t_id))
+        n = self.x.shape[0]
+        out = q(torch.cat([self.x, self.x]), torch.cat([self.t, self.t]), torch.cat([self.yc, self.yu]),
+                mask=self.mask, timestep_id=t_id)
+        return out[:n], out[n:]
+
+    def run(self, x: torch.Tensor, timestep_id: int):
+        self.x.copy_(x)
+        self.t.fill_(int(timestep_id))
+        self.graph.replay()
+        return self.cond, self.uncond
+
+
+class GraphedSampler:
+    """Lazily captures one StepGraph per smooth-quant time-range of ``qnn``."""
+
+    def __init__(self, qnn, y_cond, y_uncond, mask):
+        self.qnn, self.yc, self.yu, self.mask = qnn, y_cond, y_uncond, mask
+        self.graphs: Dict[int, StepGraph] = {}
+
+    def _range_of(self, t_id: int) -> int:
+        from .qdiff.models.quant_layer import find_interval
+        for _, layer in self.qnn.quant_layers():
+            if getattr(layer, "smooth_quant", False) and hasattr(layer, "timerange"):
+                return find_interval(layer.timerange, t_id)
+        return 0
+
+    def forward_pair(self, x, t_id: int):
+        r = self._range_of(t_id)
+        g = self.graphs.get(r)
+        if g is None:
+            g = self.graphs[r] = StepGraph(self.qnn, x, self.yc, self.yu, self.mask, t_id)
+        return g.run(x, t_id)

@@ -107,11 +107,17 @@ class TimestepEmbedder(nn.Module):
                                  nn.Linear(hidden_size, hidden_size, bias=True))
         self.frequency_embedding_size = frequency_embedding_size
 
+    _freq_cache = {}
+
     @staticmethod
     def timestep_embedding(t, dim, max_period=10000):
         half = dim // 2
-        freqs = torch.exp(-np.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
-        args = t[:, None].float() * freqs.to(t.device)[None]
+        key = (str(t.device), dim, max_period)
+        freqs = TimestepEmbedder._freq_cache.get(key)
+        if freqs is None:   # host exp() like the reference (blocks.py:430-433), uploaded once (graph-capture safe)
+            freqs = torch.exp(-np.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+            freqs = TimestepEmbedder._freq_cache[key] = freqs.to(t.device)
+        args = t[:, None].float() * freqs[None]
         emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
         if dim % 2:
             emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
@@ -452,11 +458,12 @@ class STDiT(nn.Module):
                 m = mask if mask.shape[0] == B else mask.repeat(B // mask.shape[0], 1)
                 m = m.reshape(B, -1)
                 idx = torch.nonzero(m.reshape(-1) != 0, as_tuple=False).reshape(-1)
-                lens = m.sum(dim=1).tolist()
-                self._mask_cache = (key, idx, [int(v) for v in lens])
-            _, idx, lens = self._mask_cache
+                lens = [int(v) for v in m.sum(dim=1).tolist()]
+                off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32).to(y.device)
+                self._mask_cache = (key, idx, lens, off)
+            _, idx, lens, off = self._mask_cache
             ysel = y.squeeze(1).reshape(-1, C).index_select(0, idx).reshape(1, -1, C)
-            return ysel, lens, None
+            return ysel, lens, off
         mask_ = mask if mask.shape[0] == B else mask.repeat([2, 1])
         lens = [y.shape[2]] * B
         y = y * mask_.unsqueeze(-1).unsqueeze(1)
@@ -475,13 +482,14 @@ class STDiT(nn.Module):
         t = self.t_embedder(timestep, dtype=x.dtype)
         t0 = self.t_block(t)
         y = self.y_embedder(y, self.training)
-        y, y_lens, _ = self._select_prompt_tokens(y, mask, C)
+        y, y_lens, off = self._select_prompt_tokens(y, mask, C)
 
         fused = x.is_cuda and x.dtype == torch.float16 and all(b.fused_ok() for b in self.blocks)
         if fused:
             x2 = x.reshape(B * self.num_patches, C)
             y2 = y.reshape(-1, C).contiguous()
-            off = torch.tensor(np.concatenate([[0], np.cumsum(y_lens)]), dtype=torch.int32).to(x.device, non_blocking=True)
+            if off is None:
+                off = torch.tensor(np.concatenate([[0], np.cumsum(y_lens)]), dtype=torch.int32).to(x.device)
             t0c = t0.contiguous()
             for i, block in enumerate(self.blocks):
                 block.forward_fused(x2, y2, t0c, off, self.pos_embed_temporal if i == 0 else None, B)
