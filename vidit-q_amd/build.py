@@ -8,7 +8,9 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libviditq_hip.so")
 SOURCES = ["api.hip", "rowquant.hip", "rowquant_fast.hip", "pack.hip", "gemm_i8.hip", "attention.hip", "sampler.hip", "probe.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         # keep MFMA accumulators in VGPRs: the AGPR form costs a v_accvgpr_read/write per softmax / epilogue operand
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc() -> str:

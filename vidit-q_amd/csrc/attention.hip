@@ -8,8 +8,8 @@
 // (quant_block.py:617-632 is commented out), so q, k, v, P stay fp16 / fp32.
 //
 // attn_fwd_kernel (spatial, cross, image): flash-style, one 256-thread workgroup per
-// (128-query tile, head, sequence); K tile [64 keys][D] and V^T tile [D][64 keys] staged in
-// LDS, double buffered; v_mfma_f32_32x32x16_f16 computes S^T = K Q^T (so one lane owns one
+// (128-query tile, head, sequence); K and V tiles [64 keys][D] staged row-major in LDS, double
+// buffered (V^T fragments are gathered by conflict-free column reads); v_mfma_f32_32x32x16_f16 computes S^T = K Q^T (so one lane owns one
 // query column: softmax statistics are lane-local plus one lane^32 exchange) and
 // O^T = V^T P^T (the P^T accumulator quads are already the B operand once the key order
 // inside each 16-key step is permuted identically on the V^T side).
@@ -26,16 +26,20 @@
 template <int D>
 struct AttCfg {
     static constexpr int KS = (D + 15) / 16;       // QK^T k-steps (16 dims each)
-    static constexpr int DT = (D + 31) / 32;       // O^T row tiles
+    static constexpr int DT = (D + 32) / 32;       // O^T row tiles: D dims + 1 spare row for the row sums
     static constexpr int CHD = D / 8;              // 16-byte chunks per head row
     static constexpr int KROW = (CHD | 1) * 16;    // K tile row stride (odd # of 16 B slots)
-    static constexpr int VROW = (64 + 4) * 2;      // V^T tile row stride in bytes
+    // V tile: KEY-PAIR interleaved [key/2][D | ones | pad] dwords, each dword = {V[2j][d], V[2j+1][d]}: one
+    // ds_read_b32 per lane fetches the fp16 pair an MFMA A-operand register needs (lane = output dim d), the
+    // interleave is done in registers while staging (lanes l, l^1 hold the two keys of a pair).  Column D holds
+    // {1,1} so that the P.V MFMA also yields the softmax row sums (row D of O^T).
+    static constexpr int VROW = ((D + 1 + 3) / 4 * 4) * 4 + 16;   // bytes per key pair row (16 B aligned)
     static constexpr int KTILE = 64 * KROW;
-    static constexpr int VTILE = DT * 32 * VROW;
+    static constexpr int VTILE = 32 * VROW;
     static constexpr int LDS = 2 * (KTILE + VTILE);
-    static constexpr int KCH = 64 * CHD;           // K chunks per tile
+    static constexpr int KCH = 64 * CHD;           // K (and V) chunks per tile
     static constexpr int KPT = (KCH + 255) / 256;
-    static constexpr int VPT = (CHD + 3) / 4;
+    static_assert(DT * 32 > D, "needs a spare O^T row for the row sums");
 };
 
 struct AttnArgs {
@@ -74,15 +78,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int qc = q_ok ? qi : a.Lq - 1;
     const half_t* qrow = a.q + (long)seq * a.q_seq_stride + (long)qc * a.q_tok_stride + h * D;
 
-    // zero the never-written rows d in [D, DT*32) of both V^T buffers
-    if (C::DT * 32 > D) {
-        for (int i = tid; i < 2 * (C::DT * 32 - D) * (C::VROW / 4); i += 256) {
-            const int buf = i / ((C::DT * 32 - D) * (C::VROW / 4));
-            const int rem = i % ((C::DT * 32 - D) * (C::VROW / 4));
-            reinterpret_cast<uint32_t*>(smem + 2 * C::KTILE + buf * C::VTILE + D * C::VROW)[rem] = 0u;
-        }
-    }
-
     // Q fragments (B operand): lane = query, 8 dims at ks*16 + 8g
     half8 qf[C::KS];
 #pragma unroll
@@ -99,10 +94,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY;
 
     const int nkt = (kv_len + 63) / 64;
-    int4v kr[C::KPT], vr[C::VPT];
+    int4v kr[C::KPT], vr[C::KPT];
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < C::KPT; ++i) {
@@ -111,15 +106,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 int key = kt * 64 + c / C::CHD;
                 key = key < kv_len ? key : kv_len - 1;
                 kr[i] = *reinterpret_cast<const int4v*>(kbase + (long)key * a.kv_tok_stride + (c % C::CHD) * 8);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < C::VPT; ++i) {
-            const int ch = (tid >> 6) + 4 * i;
-            if (ch < C::CHD) {
-                int key = kt * 64 + (tid & 63);
-                key = key < kv_len ? key : kv_len - 1;
-                vr[i] = *reinterpret_cast<const int4v*>(vbase + (long)key * a.kv_tok_stride + ch * 8);
+                // V: lanes c, c^1 hold the same 8-dim chunk of the two keys of pair (c>>1)/CHD
+                int vkey = kt * 64 + 2 * ((c >> 1) / C::CHD) + (c & 1);
+                vkey = vkey < kv_len ? vkey : kv_len - 1;
+                vr[i] = *reinterpret_cast<const int4v*>(vbase + (long)vkey * a.kv_tok_stride + ((c >> 1) % C::CHD) * 8);
             }
         }
     };
@@ -129,21 +119,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < C::KPT; ++i) {
             const int c = tid + i * 256;
-            if (C::KCH % 256 == 0 || c < C::KCH)
+            if (C::KCH % 256 == 0 || c < C::KCH) {
                 *reinterpret_cast<int4v*>(kt_ + (c / C::CHD) * C::KROW + (c % C::CHD) * 16) = kr[i];
-        }
-#pragma unroll
-        for (int i = 0; i < C::VPT; ++i) {
-            const int ch = (tid >> 6) + 4 * i;
-            if (ch < C::CHD) {
-                const half8 hv = __builtin_bit_cast(half8, vr[i]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *reinterpret_cast<half_t*>(vt_ + (ch * 8 + e) * C::VROW + (tid & 63) * 2) = hv[e];
+                const int odd = c & 1;
+                // exchange with the pair partner: the even lane assembles dims 0-3 of the chunk, the odd one 4-7
+                const int r0 = __shfl_xor(odd ? vr[i][0] : vr[i][2], 1);
+                const int r1 = __shfl_xor(odd ? vr[i][1] : vr[i][3], 1);
+                const uint32_t lo0 = odd ? (uint32_t)r0 : (uint32_t)vr[i][0], lo1 = odd ? (uint32_t)r1 : (uint32_t)vr[i][1];
+                const uint32_t hi0 = odd ? (uint32_t)vr[i][2] : (uint32_t)r0, hi1 = odd ? (uint32_t)vr[i][3] : (uint32_t)r1;
+                int4v pv;
+                pv[0] = (int)((lo0 & 0xffffu) | (hi0 << 16));
+                pv[1] = (int)((lo0 >> 16) | (hi0 & 0xffff0000u));
+                pv[2] = (int)((lo1 & 0xffffu) | (hi1 << 16));
+                pv[3] = (int)((lo1 >> 16) | (hi1 & 0xffff0000u));
+                *reinterpret_cast<int4v*>(vt_ + ((c >> 1) / C::CHD) * C::VROW + (((c >> 1) % C::CHD) * 8 + 4 * odd) * 4) = pv;
             }
         }
     };
 
+    // column D of both V buffers := {1.0, 1.0} (never overwritten by the staging stores)
+    if (tid < 64)
+        *reinterpret_cast<uint32_t*>(smem + 2 * C::KTILE + (tid >> 5) * C::VTILE + (tid & 31) * C::VROW + D * 4) = 0x3c003c00u;
     if (nkt > 0) {
         load_tile(0);
         store_tile(0);
@@ -171,35 +167,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 s[sc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sc], 0, 0, 0);
             }
         }
-        // ---- mask + online softmax (lane = query; keys over regs and lane^32) ----
-        float mloc = -INFINITY;
+        // ---- online softmax (lane = query; its 64 keys sit in 32 registers here and 32 in lane^32) ----
+        // VALU is the bound of this kernel (PMC: VALU busy 65 %, MFMA 18 %), so: masking only on a partial
+        // last tile (wave-uniform branch), exponent as one fma + v_exp, the O rescale only when some lane's
+        // running max moved, and NO row-sum adds: column D of V is 1.0, so row D of O^T is sum_k P.
+        if (kt * 64 + 64 > kv_len) {
 #pragma unroll
-        for (int sc = 0; sc < 2; ++sc)
+            for (int sc = 0; sc < 2; ++sc)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (key >= kv_len) s[sc][r] = -INFINITY;
-                mloc = fmaxf(mloc, s[sc][r]);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (key >= kv_len) s[sc][r] = -INFINITY;
+                }
+        }
+        float mloc = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * a.c);
-        m_run = m_new;
-        float psum = 0.f;
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * a.c);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_use * a.c;
 #pragma unroll
         for (int sc = 0; sc < 2; ++sc)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f((s[sc][r] - m_use) * a.c);
-                s[sc][r] = p;
-                psum += p;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            for (int r = 0; r < 16; ++r) s[sc][r] = __builtin_amdgcn_exp2f(fmaf(s[sc][r], a.c, -mc));
 
         // ---- O^T += V^T P^T : 4 k-steps of 16 keys ----
 #pragma unroll
@@ -211,18 +212,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 pf[e] = (half_t)s[sc][4 * rq + e];
                 pf[4 + e] = (half_t)s[sc][4 * rq + 4 + e];
             }
+            // V^T fragment (A operand: lane = output dim d, 8 keys) = 4 dwords of the key-pair image,
+            // 32 lanes read 32 consecutive dwords -> conflict-free.
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt) {
-                const uint8_t* vp = vt_ + (dt * 32 + l31) * C::VROW + (16 * kk + 4 * g) * 2;
-                const half4 v0 = *reinterpret_cast<const half4*>(vp);
-                const half4 v1 = *reinterpret_cast<const half4*>(vp + 16);
-                half8 vf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    vf[e] = v0[e];
-                    vf[4 + e] = v1[e];
-                }
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
+                const int d = dt * 32 + l31;          // d == D: the ones column; d > D: clamped, result unused
+                const uint8_t* vp = vt_ + (8 * kk + 2 * g) * C::VROW + (d <= D ? d : D) * 4;
+                int4v vw;                             // key pairs (4g+0,1) (4g+2,3) (8+4g+0,1) (8+4g+2,3) of step kk
+                vw[0] = *reinterpret_cast<const int*>(vp);
+                vw[1] = *reinterpret_cast<const int*>(vp + C::VROW);
+                vw[2] = *reinterpret_cast<const int*>(vp + 4 * C::VROW);
+                vw[3] = *reinterpret_cast<const int*>(vp + 5 * C::VROW);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, vw), pf, oacc[dt], 0, 0, 0);
             }
         }
         if (kt + 1 < nkt) store_tile(cur ^ 1);
@@ -230,7 +231,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
 
     // ---- normalise and store: lane = query, accumulator quads = 4 consecutive dims ----
-    l_run += __shfl_xor(l_run, 32);
+    // row D of O^T = sum_k P: it lives in tile D/32, register (D%32 -> (r&3)+8(r>>2)+4g) of ONE half-wave
+    constexpr int LD_T = D / 32, LD_R = D % 32;
+    constexpr int LD_G = (LD_R >> 2) & 1, LD_REG = (LD_R & 3) + 4 * (LD_R >> 3);
+    float l_run = oacc[LD_T][LD_REG];
+    l_run = __shfl(l_run, l31 + 32 * LD_G);
     const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
     if (q_ok) {
         half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi * a.o_tok_stride + h * D;

@@ -26,24 +26,41 @@ static inline int vq_check_launch() {
 }
 
 // ---- wave64 reductions (all 64 lanes receive the result) --------------------
+// DPP within rows of 16 lanes (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror: VALU-speed, no
+// LDS crossbar round trip as __shfl_xor/ds_bpermute has), then the four row results through
+// v_readlane.  6 dependent ds_bpermute (~100+ cycles each) per reduction were a visible part of the
+// quantizer kernels' latency chain.
+#define VQ_DPP_STEP(T_, OP_, v_, ctrl_)                                                             \
+    v_ = OP_(v_, __builtin_bit_cast(T_, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_), ctrl_, 0xf, 0xf, true)))
+#define VQ_WAVE_REDUCE(T_, OP_, v_)                                                                 \
+    VQ_DPP_STEP(T_, OP_, v_, 0xB1);  /* quad_perm [1,0,3,2] */                                      \
+    VQ_DPP_STEP(T_, OP_, v_, 0x4E);  /* quad_perm [2,3,0,1] */                                      \
+    VQ_DPP_STEP(T_, OP_, v_, 0x141); /* row_half_mirror      */                                      \
+    VQ_DPP_STEP(T_, OP_, v_, 0x140); /* row_mirror           */                                      \
+    {                                                                                               \
+        const int b_ = __builtin_bit_cast(int, v_);                                                 \
+        const T_ r0_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 0));                    \
+        const T_ r1_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 16));                   \
+        const T_ r2_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 32));                   \
+        const T_ r3_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 48));                   \
+        v_ = OP_(OP_(r0_, r1_), OP_(r2_, r3_));                                                     \
+    }
+__device__ __forceinline__ float vq_addf(float a, float b) { return a + b; }
+__device__ __forceinline__ int vq_addi(int a, int b) { return a + b; }
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    VQ_WAVE_REDUCE(float, fmaxf, v)
     return v;
 }
 __device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    VQ_WAVE_REDUCE(float, fminf, v)
     return v;
 }
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    VQ_WAVE_REDUCE(float, vq_addf, v)
     return v;
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    VQ_WAVE_REDUCE(int, vq_addi, v)
     return v;
 }
 
