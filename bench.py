@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region (no HIP graph)")
+    ap.add_argument("--one-stream", action="store_true", help="cond and uncond serialised on one stream")
     return ap.parse_args()
 
 
@@ -115,7 +116,7 @@ def main():
         idx = list(range(sch.num_timesteps))[::-1]
         buf = torch.empty_like(x)
 
-        gs = None if a.no_graph else graph.GraphedSampler(qnn, y_c, y_u, mask)
+        gs = None if a.no_graph else graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
 
         def step(j, x, buf, eager=False):
             i = idx[j % len(idx)]
@@ -185,7 +186,7 @@ def main():
                 "config": {"workload": "OpenSORA STDiT-XL/2 16x512x512 W8A8 (w8a8_dynamic.yaml), 1 prompt per GPU, "
                                        "DDIM-100 schedule, cfg 4.0, cfg_split, depth %d" % a.depth,
                            "tokens": 16384, "prompts_in_flight": world, "sharding": "prompt -> rank (no in-step collective)",
-                           "status_word": status, "hip_graph": not a.no_graph},
+                           "status_word": status, "hip_graph": not a.no_graph, "cond_uncond_streams": 1 if (a.one_stream or a.no_graph) else 2},
                 "whole_step_int8_frac": 43.87e12 * (a.depth / 28.0) * value / world / PEAK_INT8,
                 "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:

@@ -226,3 +226,22 @@ def test_block_matches_oracle_at_xl_width(dev, ops):
     cfgd = dict(T=4, S=64, H=16, depth=1, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(4, 16, 16))
     ref = sr.stdit_forward(sd, cfgd, x.cpu().half().float(), t.cpu(), y.cpu().float(), mask, sr.QSpec(w_bits=8))
     assert rel_l2(out.cpu(), ref) < 5e-3
+
+
+def test_hip_graph_two_stream_step_equals_eager(dev, ops):
+    """The captured step (cond and uncond as parallel graph branches on two HIP streams) must reproduce
+    the eager, single-stream forwards bit for bit, also after replay with new latent contents."""
+    from viditq_amd.graph import GraphedSampler
+    g = load_npz("tiny_stdit_w8a8.npz")
+    qnn = _build(g, dev, 8)
+    y, mask = g["y"].half().to(dev), g["mask"].to(dev)
+    gs = GraphedSampler(qnn, y[:1], y[1:], mask, two_streams=True)
+    for seed, t_id in ((1, 721), (2, 300), (3, 721)):
+        x = torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(seed)).to(dev)
+        t = torch.full((1,), t_id, device=dev, dtype=torch.long)
+        cond_e = qnn(x, t, y[:1], mask=mask, timestep_id=t_id).clone()
+        unc_e = qnn(x, t, y[1:], mask=mask, timestep_id=t_id).clone()
+        cond_g, unc_g = gs.forward_pair(x, t_id)
+        torch.cuda.synchronize()
+        assert torch.equal(cond_g, cond_e) and torch.equal(unc_g, unc_e)
+    assert len(gs.graphs) == 1

@@ -19,8 +19,14 @@ class StepGraph:
     """cond/uncond forwards of a QuantModel for one prompt as a replayable HIP graph."""
 
     def __init__(self, qnn, x: torch.Tensor, y_cond: torch.Tensor, y_uncond: torch.Tensor,
-                 mask: Optional[torch.Tensor], timestep_id: int, warmup: int = 2):
+                 mask: Optional[torch.Tensor], timestep_id: int, warmup: int = 2, two_streams: bool = True):
         self.qnn = qnn
+        # cond and uncond are independent chains: captured as two parallel branches of the graph (fork /
+        # join through a second HIP stream) so that the HBM-bound kernels of one chain (quantizers,
+        # temporal attention: few VGPRs, no LDS) can run on CUs whose MFMA pipes the other chain's GEMM
+        # workgroups keep busy
+        self.two_streams = two_streams
+        self.side = torch.cuda.Stream() if two_streams else None
         self.x = x.clone()
         self.t = torch.full((x.shape[0],), int(timestep_id), device=x.device, dtype=torch.long)
         self.yc, self.yu = y_cond.clone(), y_uncond.clone()
@@ -38,6 +44,14 @@ class StepGraph:
 
     def _forward(self, t_id):
         q = self.qnn
+        if self.cfg_split and self.two_streams:
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                unc = q(self.x, self.t, self.yu, mask=self.mask, timestep_id=t_id)
+            cond = q(self.x, self.t, self.yc, mask=self.mask, timestep_id=t_id)
+            cur.wait_stream(self.side)
+            return cond, unc
         if self.cfg_split:
             return (q(self.x, self.t, self.yc, mask=self.mask, timestep_id=t_id),
                     q(self.x, self.t, self.yu, mask=self.mask, timestep_id=t_id))
@@ -56,8 +70,9 @@ class StepGraph:
 class GraphedSampler:
     """Lazily captures one StepGraph per smooth-quant time-range of ``qnn``."""
 
-    def __init__(self, qnn, y_cond, y_uncond, mask):
+    def __init__(self, qnn, y_cond, y_uncond, mask, two_streams: bool = True):
         self.qnn, self.yc, self.yu, self.mask = qnn, y_cond, y_uncond, mask
+        self.two_streams = two_streams
         self.graphs: Dict[int, StepGraph] = {}
 
     def _range_of(self, t_id: int) -> int:
@@ -71,5 +86,6 @@ class GraphedSampler:
         r = self._range_of(t_id)
         g = self.graphs.get(r)
         if g is None:
-            g = self.graphs[r] = StepGraph(self.qnn, x, self.yc, self.yu, self.mask, t_id)
+            g = self.graphs[r] = StepGraph(self.qnn, x, self.yc, self.yu, self.mask, t_id,
+                                           two_streams=self.two_streams)
         return g.run(x, t_id)
