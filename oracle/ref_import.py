@@ -133,7 +133,7 @@ def install():
         if attn_bias is None:
             a = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * scale
             o = torch.einsum("bhqk,bkhd->bqhd", a.softmax(-1), v.float())
-            return o.to(q.dtype)
+            return o.to(q.dtype).contiguous()
         outs = []
         qs = ks = 0
         for ql, kl in zip(attn_bias.q_lens, attn_bias.k_lens):
@@ -142,7 +142,7 @@ def install():
             outs.append(torch.einsum("bhqk,bkhd->bqhd", a.softmax(-1), vv.float()))
             qs += ql
             ks += kl
-        return torch.cat(outs, dim=1).to(q.dtype)
+        return torch.cat(outs, dim=1).to(q.dtype).contiguous()
 
     fmha = _mod("xformers.ops.fmha", BlockDiagonalMask=BlockDiagonalMask)
     ops = _mod("xformers.ops", memory_efficient_attention=memory_efficient_attention, fmha=fmha)
@@ -189,6 +189,64 @@ def load():
     ns.STDiT, ns.STDiTBlock = st.STDiT, st.STDiTBlock
     ns.blocks = bl
     ns.Cfg = Cfg
+    return ns
+
+
+def load_t2i():
+    """PixArt side of the reference (t2i/): extra stubs of SURVEY Appendix D - minimal restatements of the
+    timm==0.6.12 constructors the reference subclasses (Attention, Mlp, PatchEmbed), mmcv.Registry, and
+    the two helper modules that import torchvision / mmcv."""
+    install()
+    import importlib
+    t2i = os.path.join(REF_ROOT, "t2i")
+    if t2i not in sys.path:
+        sys.path.insert(0, t2i)
+
+    class Attention(nn.Module):      # timm.models.vision_transformer.Attention.__init__ (0.6.12)
+        def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0, **kw):
+            super().__init__()
+            self.num_heads = num_heads
+            self.scale = (dim // num_heads) ** -0.5
+            self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+            self.attn_drop = nn.Dropout(attn_drop)
+            self.proj = nn.Linear(dim, dim)
+            self.proj_drop = nn.Dropout(proj_drop)
+
+    class PatchEmbed(nn.Module):
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True, bias=True):
+            super().__init__()
+            self.patch_size = (patch_size, patch_size)
+            self.num_patches = (img_size // patch_size) ** 2
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+
+        def forward(self, x):
+            return self.proj(x).flatten(2).transpose(1, 2)
+
+    vt = sys.modules["timm.models.vision_transformer"]
+    vt.Attention, vt.PatchEmbed = Attention, PatchEmbed
+
+    class Registry:
+        def __init__(self, *a, **k):
+            pass
+
+        def register_module(self, *a, **k):
+            def deco(f):
+                return f
+            return deco
+
+    _mod("mmcv", Registry=Registry)
+    _ns("diffusion", os.path.join(t2i, "diffusion"))
+    _ns("diffusion.model", os.path.join(t2i, "diffusion/model"))
+    _ns("diffusion.model.nets", os.path.join(t2i, "diffusion/model/nets"))
+    _ns("diffusion.utils", os.path.join(t2i, "diffusion/utils"))
+    _mod("diffusion.model.utils", auto_grad_checkpoint=lambda m, *a, **k: m(*a, **k),
+         to_2tuple=lambda v: v if isinstance(v, tuple) else (v, v), set_grad_checkpoint=lambda *a, **k: None)
+    _mod("diffusion.utils.logger", get_root_logger=lambda *a, **k: None)
+    ns = load()
+    ms = importlib.import_module("diffusion.model.nets.PixArtMS")
+    dq = importlib.import_module("qdiff.models.dit_quant_layer")
+    ns.PixArtMS, ns.PixArtMSBlock = ms.PixArtMS, ms.PixArtMSBlock
+    ns.QuantAttnLinearImg, ns.QuantCrossAttnLinearImg = dq.QuantAttnLinearImg, dq.QuantCrossAttnLinearImg
     return ns
 
 

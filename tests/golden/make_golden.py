@@ -312,13 +312,60 @@ def tiny_stdit(R):
     npz("tiny_stdit_w4a8.npz", **out)
 
 
+# ----------------------------------------------------------------------------- 4. tiny PixArtMS
+def tiny_pixart():
+    R = ref_import.load_t2i()
+    out = {}
+    torch.manual_seed(3)
+    m = R.PixArtMS(input_size=16, depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if p_.abs().sum() == 0:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
+        for p_ in m.parameters():
+            p_.copy_(h(p_))
+    m.eval()
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.clone()
+    x = h(torch.randn(2, 4, 16, 16, generator=g))
+    y = h(torch.randn(2, 1, 12, 32, generator=g) * 0.5)
+    mask = torch.zeros(2, 12, dtype=torch.int64)
+    mask[0, :9] = 1
+    mask[1, :12] = 1
+    t = torch.tensor([500, 500])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    with torch.no_grad():
+        out["fp"] = m(x, t.float(), y, mask=mask)
+        qnn = R.QuantModel(m, ref_import.wq_cfg(8), ref_import.aq_cfg(T=1, S=64, n_prompt=12), model_type="pixart")
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.fp_layer_list = ["x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder"]
+        qnn.set_quant_state(True, False)
+        qnn(x, t, y, mask=mask)
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_init_done("activation")
+        qnn.set_quant_state(True, True)
+        out["w8a8"] = qnn(x, t, y, mask=mask)                       # B = 2: per-token scales shared over the batch
+        out["w8a8_b1"] = qnn(x[:1], t[:1], y[:1], mask=mask[:1])
+        from diffusion.model.nets.PixArt import get_2d_sincos_pos_embed
+        out["pos_embed"] = torch.from_numpy(get_2d_sincos_pos_embed(64, (8, 8), pe_interpolation=1.0, base_size=8)).float()[None]
+        qd = qnn.get_quant_params_dict()
+        for name, (bufs, params) in qd.items():
+            for bn, bv in bufs.items():
+                if bv is not None:
+                    out["qp/%s/%s" % (name, bn)] = bv
+    npz("tiny_pixart_w8a8.npz", **out)
+
+
 def main():
     assert ref_import.available(), "needs /root/reference"
-    R = ref_import.load()
     torch.set_grad_enabled(False)
-    quantizer_kats(R)
-    layer_kats(R)
-    tiny_stdit(R)
+    if "--pixart-only" not in sys.argv:
+        R = ref_import.load()
+        quantizer_kats(R)
+        layer_kats(R)
+        tiny_stdit(R)
+    tiny_pixart()
 
 
 if __name__ == "__main__":

@@ -245,3 +245,40 @@ def test_hip_graph_two_stream_step_equals_eager(dev, ops):
         torch.cuda.synchronize()
         assert torch.equal(cond_g, cond_e) and torch.equal(unc_g, unc_e)
     assert len(gs.graphs) == 1
+
+
+def test_tiny_pixart_w8a8_fused_path(dev, ops):
+    """PixArt-MS through QuantModel(model_type='pixart') vs the reference golden: fused-qkv
+    QuantAttnLinearImg, varlen cross attention, quantized final_layer (t2i FP list), B = 2 shared scales."""
+    import viditq_amd  # noqa
+    from viditq_amd.qdiff.models import QuantAttnLinearImg, QuantCrossAttnLinearImg, QuantModel
+    from viditq_amd.qdiff.quantizer import BaseQuantizer
+    from viditq_amd.t2i import PixArtMS
+    g = load_npz("tiny_pixart_w8a8.npz")
+    m = PixArtMS(input_size=16, depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32,
+                 dtype=torch.float16)
+    m.load_state_dict(state_dict_of(g), strict=True)
+    m = m.half().to(dev).eval()
+    wq, aq = _cfgs(8)
+    aq["n_spatial_token"], aq["n_temporal_token"] = 64, 1
+    qnn = QuantModel(m, wq, aq, model_type="pixart")
+    assert isinstance(qnn.model.blocks[0].attn.qkv, QuantAttnLinearImg)
+    assert isinstance(qnn.model.blocks[0].cross_attn.kv_linear, QuantCrossAttnLinearImg)
+    qnn.set_module_name_for_quantizer(qnn.model)
+    qnn.fp_layer_list = ["x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder"]
+    qp = quant_params_of(g)
+    full = {mod.module_name: [qp.get(mod.module_name, {}), {}] for mod in qnn.model.modules()
+            if isinstance(mod, BaseQuantizer)}
+    qnn.set_quant_params_dict(full)
+    qnn.set_quant_init_done("weight")
+    qnn.set_quant_init_done("activation")
+    qnn.set_quant_state(True, True)
+    assert all(b.fused_ok() for b in qnn.model.blocks)
+    assert qnn.model.final_layer.linear.get_quant_state() == (True, True)
+    x, y, mask, t = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev), g["t"].to(dev)
+    out = qnn(x, t, y, mask=mask)
+    assert rel_l2(out.cpu().float(), g["w8a8"]) < 5e-3
+    out1 = qnn(x[:1], t[:1], y[:1], mask=mask[:1])
+    assert rel_l2(out1.cpu().float(), g["w8a8_b1"]) < 5e-3
+    qnn.set_quant_state(False, False)
+    assert rel_l2(qnn(x, t, y, mask=mask).cpu().float(), g["fp"]) < 3e-3

@@ -125,3 +125,19 @@ def test_tiny_stdit_w4a8_timerange_and_mixed_precision():
     spec.layer_w_bits = {"blocks.0.mlp.fc1": 8, "blocks.1.attn.q": 8}
     out = sr.stdit_forward(sd, TINY_CFG, x, torch.tensor([721]), y[:1], mask, spec)
     assert rel_l2(out, g["w4a8_mp_cond_t721"]) < 1e-5
+
+
+def test_tiny_pixart_w8a8():
+    from oracle import pixart_ref as pr
+    g = load_npz("tiny_pixart_w8a8.npz")
+    sd = state_dict_of(g)
+    cfg = dict(H=4, depth=2, patch=2, out_ch=8)
+    x, y, mask, t = g["x"], g["y"], g["mask"], g["t"]
+    fp = pr.pixart_forward(sd, cfg, x, t, y, mask, sr.QSpec(quant=False), g["pos_embed"])
+    assert rel_l2(fp, g["fp"]) < 1e-5
+    spec = sr.QSpec(w_bits=8, fp_layers=pr.T2I_FP_LAYERS)      # final_layer IS quantized in t2i (Appendix B)
+    out = pr.pixart_forward(sd, cfg, x, t, y, mask, spec, g["pos_embed"])
+    assert rel_l2(out, g["w8a8"]) < 1e-5
+    out1 = pr.pixart_forward(sd, cfg, x[:1], t[:1], y[:1], mask[:1], spec, g["pos_embed"])
+    assert rel_l2(out1, g["w8a8_b1"]) < 1e-5
+    assert rel_l2(out[:1], out1) > 1e-4                         # batch-shared token scales change the result

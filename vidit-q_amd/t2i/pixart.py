@@ -1,0 +1,302 @@
+"""PixArt-alpha / PixArt-Sigma (MS) block and model forward on the gfx950 kernels.
+
+Module / parameter names mirror t2i/diffusion/model/nets/{PixArt,PixArtMS,PixArt_blocks}.py so the
+name routing of QuantModel(model_type='pixart') applies unchanged:
+  blocks.{i}.attn.{qkv,proj} -> QuantAttnLinearImg      (fused qkv Linear, PixArt_blocks.py:132)
+  blocks.{i}.cross_attn.{q_linear,kv_linear,proj} -> QuantCrossAttnLinearImg
+  blocks.{i}.mlp.{fc1,fc2}, final_layer.linear, t_block.1, t_embedder.mlp.*, y_embedder.y_proj.* -> QuantLayer
+  x_embedder.proj (Conv2d) -> QuantLayer, kept FP by the t2i FP list (quant_txt2img.py:293-295).
+Unlike t2v, final_layer.linear is NOT in the t2i FP list and is quantized.
+
+Block = STDiT block without the temporal branch (PixArtMS.py:71-79); the fused route reuses the same
+kernels: LN+modulate+quant -> fused-qkv int8 GEMM -> flash attention over N tokens (4096 at 1024^2)
+-> proj GEMM (+gate, +residual) -> varlen cross attention -> MLP.  kv-compression (sr_ratio > 1) and
+qk_norm are not used by the quantized configs and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..qdiff.models.quant_block import QuantAttention
+from ..qdiff.models.quant_layer import QuantLayer
+from ..qdiff.quantizer.dynamic_quantizer import DynamicActQuantizer
+from ..t2v.stdit import (CaptionEmbedder, Mlp, MultiHeadCrossAttention, T2IFinalLayer, TimestepEmbedder, approx_gelu,
+                         get_1d_sincos_pos_embed_from_grid, t2i_modulate)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, pe_interpolation=1.0, base_size=16):
+    """PixArt.py:258-275."""
+    if isinstance(grid_size, int):
+        grid_size = (grid_size, grid_size)
+    grid_h = np.arange(grid_size[0], dtype=np.float32) / (grid_size[0] / base_size) / pe_interpolation
+    grid_w = np.arange(grid_size[1], dtype=np.float32) / (grid_size[1] / base_size) / pe_interpolation
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0).reshape([2, 1, grid_size[1], grid_size[0]])
+    emb_h = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0])
+    emb_w = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])
+    return np.concatenate([emb_h, emb_w], axis=1)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size=2, in_chans=4, embed_dim=1152, bias=True):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class SizeEmbedder(TimestepEmbedder):
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__(hidden_size=hidden_size, frequency_embedding_size=frequency_embedding_size)
+        self.outdim = hidden_size
+
+    def forward(self, s, bs):
+        if s.ndim == 1:
+            s = s[:, None]
+        if s.shape[0] != bs:
+            s = s.repeat(bs // s.shape[0], 1)
+        b, dims = s.shape
+        s_freq = self.timestep_embedding(s.reshape(-1), self.frequency_embedding_size)
+        s_emb = self.mlp(s_freq.to(next(self.parameters()).dtype))
+        return s_emb.reshape(b, dims * self.outdim)
+
+
+class AttentionKVCompress(nn.Module):
+    """Self-attention with a fused qkv Linear (PixArt_blocks.py:63-160, sr_ratio == 1)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=True, sampling=None, sr_ratio=1, qk_norm=False):
+        super().__init__()
+        if sr_ratio != 1 or qk_norm:
+            raise NotImplementedError("kv compression / qk_norm are not used by the quantized PixArt configs")
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.core = QuantAttention(num_heads, self.head_dim)
+
+    def forward(self, x, mask=None, HW=None, block_id=None):
+        B, N, C = x.shape
+        dt = x.dtype
+        qkv = self.qkv(x).reshape(B * N, 3 * C).half().contiguous()   # q | k | v column blocks (qkv.reshape(B,N,3,C))
+        o = self.core.spatial(qkv, B, N)
+        return self.proj(o.reshape(B, N, C).to(dt))
+
+
+class PixArtMSBlock(nn.Module):
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, **unused):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.attn = AttentionKVCompress(hidden_size, num_heads=num_heads, qkv_bias=True)
+        self.cross_attn = MultiHeadCrossAttention(hidden_size, num_heads)
+        self.norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.mlp = Mlp(in_features=hidden_size, hidden_features=int(hidden_size * mlp_ratio), act_layer=approx_gelu)
+        self.scale_shift_table = nn.Parameter(torch.randn(6, hidden_size) / hidden_size ** 0.5)
+
+    def hot_layers(self) -> List[nn.Module]:
+        return [self.attn.qkv, self.attn.proj, self.cross_attn.q_linear, self.cross_attn.kv_linear,
+                self.cross_attn.proj, self.mlp.fc1, self.mlp.fc2]
+
+    def fused_ok(self) -> bool:
+        for m in self.hot_layers():
+            if not (isinstance(m, QuantLayer) and m.int_route_ok()):
+                return False
+            if not isinstance(m.act_quantizer, DynamicActQuantizer) and m.act_quantizer.per_group:
+                return False
+        return True
+
+    def forward(self, x, y, t, mask=None, HW=None, **kwargs):
+        """PixArtMS.py:71-79 (reference data flow)."""
+        B, N, C = x.shape
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = (
+            self.scale_shift_table[None] + t.reshape(B, 6, -1)).chunk(6, dim=1)
+        x = x + gate_msa * self.attn(t2i_modulate(self.norm1(x), shift_msa, scale_msa), HW=HW)
+        x = x + self.cross_attn(x, y, mask)
+        x = x + gate_mlp * self.mlp(t2i_modulate(self.norm2(x), shift_mlp, scale_mlp))
+        return x
+
+    def forward_fused(self, x2, y2, t0, kv_off, B):
+        """In-place update of x2 [B*N, C] fp16 (hot path; same kernel sequence as the STDiT block minus
+        the temporal branch)."""
+        C = self.hidden_size
+        M = x2.shape[0]
+        N = M // B
+        a1, ca, fc1, fc2 = self.attn, self.cross_attn, self.mlp.fc1, self.mlp.fc2
+
+        def sv(layer):
+            r, alpha = layer._range_and_alpha()
+            return r, layer.smooth_vector(r, alpha)
+
+        mod = ops.adaln_table(self.scale_shift_table.detach(), t0.reshape(B, -1))
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = [mod[j] for j in range(6)]
+        x3 = x2.view(B, N, C)
+        st = a1.qkv.status
+        r, s = sv(a1.qkv)
+        qa = ops.ln_modulate_rowquant(x3, shift_msa, scale_msa, 1e-6, smooth=[s], n_bits=a1.qkv.act_quantizer.n_bits,
+                                      status=st)[0]
+        qkv = ops.gemm_i8(qa, a1.qkv.packed_weight(r, s), bias=a1.qkv.bias_f32())
+        att_o = a1.core.spatial(qkv, B, N)
+        r, s = sv(a1.proj)
+        qa = a1.proj.quantize_input(att_o.view(B, N, C), s)
+        ops.gemm_i8(qa, a1.proj.packed_weight(r, s), bias=a1.proj.bias_f32(), out=x2, epilogue=ops.EPI_GATE_RESID,
+                    resid=x2, gate=gate_msa, rows_per_gate=N)
+        r, s = sv(ca.q_linear)
+        q = ops.gemm_i8(ca.q_linear.quantize_input(x3, s), ca.q_linear.packed_weight(r, s), bias=ca.q_linear.bias_f32())
+        r, s = sv(ca.kv_linear)
+        kv = ops.gemm_i8(ca.kv_linear.quantize_input(y2.view(1, -1, C), s), ca.kv_linear.packed_weight(r, s),
+                         bias=ca.kv_linear.bias_f32())
+        att_o = ca.core.cross(q, kv, kv_off, B, N, out=att_o)
+        r, s = sv(ca.proj)
+        ops.gemm_i8(ca.proj.quantize_input(att_o.view(B, N, C), s), ca.proj.packed_weight(r, s),
+                    bias=ca.proj.bias_f32(), out=x2, epilogue=ops.EPI_RESID, resid=x2)
+        r, s = sv(fc1)
+        qa = ops.ln_modulate_rowquant(x3, shift_mlp, scale_mlp, 1e-6, smooth=[s], n_bits=fc1.act_quantizer.n_bits,
+                                      status=st)[0]
+        h = ops.gemm_i8(qa, fc1.packed_weight(r, s), bias=fc1.bias_f32(), epilogue=ops.EPI_GELU)
+        r, s = sv(fc2)
+        ops.gemm_i8(fc2.quantize_input(h.view(B, N, -1), s), fc2.packed_weight(r, s), bias=fc2.bias_f32(), out=x2,
+                    epilogue=ops.EPI_GATE_RESID, resid=x2, gate=gate_mlp, rows_per_gate=N)
+        return x2
+
+
+class PixArtMS(nn.Module):
+    """PixArt-Sigma / multi-scale (PixArtMS.py:82-211); with a fixed input size it is PixArt-alpha
+    (PixArt.py:60-190: same forward with a constant positional embedding)."""
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, class_dropout_prob=0.1, learn_sigma=True, pred_sigma=True, drop_path=0.0,
+                 caption_channels=4096, pe_interpolation=1.0, config=None, model_max_length=120,
+                 micro_condition=False, qk_norm=False, kv_compress_config=None, dtype=torch.float32, **kwargs):
+        super().__init__()
+        self.pred_sigma = pred_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if pred_sigma else in_channels
+        self.patch_size, self.num_heads, self.depth = patch_size, num_heads, depth
+        self.hidden_size = hidden_size
+        self.pe_interpolation = pe_interpolation
+        self.base_size = input_size // patch_size
+        self.dtype = dtype
+        self.x_embedder = PatchEmbed(patch_size, in_channels, hidden_size, bias=True)
+        # state-dict compatibility with PixArt.py:99 (MS recomputes the embedding per call; PixArt-alpha
+        # checkpoints carry it as a buffer)
+        self.register_buffer("pos_embed", torch.zeros(1, (input_size // patch_size) ** 2, hidden_size))
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.t_block = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+        self.y_embedder = CaptionEmbedder(in_channels=caption_channels, hidden_size=hidden_size,
+                                          uncond_prob=class_dropout_prob, act_layer=approx_gelu,
+                                          token_num=model_max_length)
+        self.micro_conditioning = micro_condition
+        if micro_condition:
+            self.csize_embedder = SizeEmbedder(hidden_size // 3)
+            self.ar_embedder = SizeEmbedder(hidden_size // 3)
+        if kv_compress_config is not None and kv_compress_config.get("kv_compress_layer"):
+            raise NotImplementedError("kv compression is not used by the quantized PixArt configs")
+        self.blocks = nn.ModuleList([PixArtMSBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
+        self.final_layer = T2IFinalLayer(hidden_size, patch_size * patch_size, self.out_channels)
+        self.h = self.w = 0
+        self._pe_cache = {}
+        self._mask_cache = None
+        self.initialize()
+
+    def initialize(self):
+        def _basic_init(module):
+            if isinstance(module, nn.Linear):
+                torch.nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+        self.apply(_basic_init)
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        nn.init.normal_(self.t_block[1].weight, std=0.02)
+        nn.init.normal_(self.y_embedder.y_proj.fc1.weight, std=0.02)
+        nn.init.normal_(self.y_embedder.y_proj.fc2.weight, std=0.02)
+        for block in self.blocks:
+            nn.init.constant_(block.cross_attn.proj.weight, 0)
+            nn.init.constant_(block.cross_attn.proj.bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    def _pos_embed(self, device, dtype):
+        key = (self.h, self.w, str(device), dtype)
+        pe = self._pe_cache.get(key)
+        if pe is None:
+            pe = torch.from_numpy(get_2d_sincos_pos_embed(self.hidden_size, (self.h, self.w),
+                                                          pe_interpolation=self.pe_interpolation,
+                                                          base_size=self.base_size)).unsqueeze(0).to(device).to(dtype)
+            self._pe_cache[key] = pe
+        return pe
+
+    def _select(self, y, mask, C):
+        B = y.shape[0]
+        if mask is None:
+            return y.squeeze(1).reshape(1, -1, C), [y.shape[2]] * B
+        key = (mask.data_ptr(), mask._version, tuple(mask.shape), B)
+        if self._mask_cache is None or self._mask_cache[0] != key:
+            m = mask if mask.shape[0] == B else mask.repeat(B // mask.shape[0], 1)
+            m = m.reshape(B, -1)
+            idx = torch.nonzero(m.reshape(-1) != 0, as_tuple=False).reshape(-1)
+            self._mask_cache = (key, idx, [int(v) for v in m.sum(dim=1).tolist()])
+        _, idx, lens = self._mask_cache
+        return y.squeeze(1).reshape(-1, C).index_select(0, idx).reshape(1, -1, C), lens
+
+    def forward(self, x, timestep, y, mask=None, data_info=None, **kwargs):
+        """PixArtMS.py:165-211."""
+        bs = x.shape[0]
+        x = x.to(self.dtype)
+        timestep = timestep.to(self.dtype)
+        y = y.to(self.dtype)
+        C = self.hidden_size
+        self.h, self.w = x.shape[-2] // self.patch_size, x.shape[-1] // self.patch_size
+        x = self.x_embedder(x) + self._pos_embed(x.device, self.dtype)
+        t = self.t_embedder(timestep, dtype=x.dtype)
+        if self.micro_conditioning:
+            c_size, ar = data_info["img_hw"].to(self.dtype), data_info["aspect_ratio"].to(self.dtype)
+            t = t + torch.cat([self.csize_embedder(c_size, bs), self.ar_embedder(ar, bs)], dim=1)
+        t0 = self.t_block(t)
+        y = self.y_embedder(y, self.training)
+        y, y_lens = self._select(y, mask, C)
+        x = x.contiguous()
+        if x.is_cuda and x.dtype == torch.float16 and all(b.fused_ok() for b in self.blocks):
+            N = x.shape[1]
+            x2 = x.reshape(bs * N, C)
+            y2 = y.reshape(-1, C).contiguous()
+            off = torch.tensor(np.concatenate([[0], np.cumsum(y_lens)]), dtype=torch.int32).to(x.device)
+            t0c = t0.contiguous()
+            for block in self.blocks:
+                block.forward_fused(x2, y2, t0c, off, bs)
+            x = x2.reshape(bs, N, C)
+        else:
+            for block in self.blocks:
+                x = block(x, y, t0, y_lens, (self.h, self.w))
+        x = self.final_layer(x, t)
+        return self.unpatchify(x)
+
+    def forward_with_dpmsolver(self, x, timestep, y, data_info=None, **kwargs):
+        """PixArtMS.py:213-218: DPM-Solver needs no variance prediction."""
+        return self.forward(x, timestep, y, data_info=data_info, **kwargs).chunk(2, dim=1)[0]
+
+    def unpatchify(self, x):
+        c, p = self.out_channels, self.patch_size
+        assert self.h * self.w == x.shape[1]
+        x = x.reshape(x.shape[0], self.h, self.w, p, p, c)
+        x = torch.einsum("nhwpqc->nchpwq", x)
+        return x.reshape(x.shape[0], c, self.h * p, self.w * p)
+
+
+PixArt = PixArtMS
+
+
+def PixArtMS_XL_2(**kwargs):
+    return PixArtMS(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)
+
+
+def PixArt_XL_2(**kwargs):
+    return PixArtMS(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)
