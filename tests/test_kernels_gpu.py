@@ -168,6 +168,23 @@ def test_gemm_low_bit_weights(ops, dev, w_bits):
     assert rel_l2(out, ref) < 5e-4
 
 
+@pytest.mark.parametrize("variant", [0, 10])
+@pytest.mark.parametrize("M,N,K", [(64, 48, 96), (300, 292, 128), (512, 576, 1152), (130, 1152, 4608)])
+def test_gemm_w4a8_vs_oracle(ops, dev, variant, M, N, K):
+    """Nibble-packed weights through the register-staged kernel (0) and the LDS-DMA ring (10: packed
+    rows are DMA-ed as 32-byte rows and expanded in registers), ragged M / N / K tiles included."""
+    x = h16(1, M, K, scale=1.5, seed=M + K)
+    W = h16(N, K, scale=0.04, seed=N)
+    b = h16(N, scale=0.1, seed=5).float()
+    ref = _oracle_linear(x, W, b, 4, 8)[0]
+    qa = ops.rowquant(x.to(dev))
+    d, z = ops.weight_minmax(W.to(dev), 4)
+    pw = ops.pack_weight(W.to(dev), d, z, 4)
+    out = ops.gemm_i8(qa, pw, bias=b.to(dev), variant=variant).cpu().float()
+    assert rel_l2(out, ref) < 5e-4
+    assert (out - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
 def test_gemm_epilogues(ops, dev):
     B, n_tok, N, K = 2, 80, 96, 128
     M = B * n_tok

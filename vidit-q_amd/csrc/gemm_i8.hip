@@ -24,6 +24,7 @@
 // Roofline: MFMA-bound (int8 dense peak 5.03 POPS); algorithmic bytes M*K + N*K(/2) + 2*M*N (+2*M*N
 // when a residual is read).
 #include <stdlib.h>
+#include <type_traits>
 #include "vq_common.h"
 
 template <int BK>
@@ -493,7 +494,7 @@ static int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
 //     earlier) has landed and every wave has issued its last read of stage kt-1, so the same point
 //     re-issues DMA(kt+2) into that stage; the vmcnt(0) of the barrier only ever waits for a transfer
 //     that had a whole tile of MFMAs to complete.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER, bool W4>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(GemmArgs a) {
     // NSTAGE == 3: one DMA batch in flight (plain __syncthreads, vmcnt(0)).
     // NSTAGE == 4: TWO batches in flight: the mid-tile wait is a COUNTED s_waitcnt vmcnt(P) (P = this
@@ -505,8 +506,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
     constexpr int AHEAD = NSTAGE - 1;                 // DMA distance in k-tiles
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int STAGE = (BM + BN) * BK;
-    constexpr int PIECES = (BM + BN) / 16;
+    // W4: nibble-packed weight rows are 32 bytes per k-tile (pack.hip layout), expanded to int8 operand
+    // words in registers right before the MFMA: half the weight bytes through HBM, L2 and LDS
+    constexpr int WROW = W4 ? 32 : 64;                // bytes per weight row and k-tile
+    constexpr int XP = BM / 16, WP = BN * WROW / 1024;  // 1 KiB DMA pieces
+    static_assert(BN * WROW % 1024 == 0, "whole pieces");
+    constexpr int STAGE = BM * BK + BN * WROW;
+    constexpr int PIECES = XP + WP;
     constexpr int PPW = (PIECES + NW - 1) / NW;
     constexpr int PLAST = PIECES - (PPW - 1) * NW;    // waves < PLAST issue PPW pieces, the others PPW-1
     constexpr int BAR_AT = TN >= 4 ? TN - 3 : 0;
@@ -533,16 +539,26 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int p = wave + i * NW;
-        const int r = p * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ swz16(r);
-        if (r < BM) {
+        if (p < XP) {
+            const int r = p * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ swz16(r);
             int gm = m0 + r;
             gm = gm < a.M ? gm : a.M - 1;
             soff[i] = (uint32_t)gm * (uint32_t)a.Kp + c * 16;
-        } else {
-            int gn = n0 + (r - BM);
+        } else if (!W4) {
+            const int r = (p - XP) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ swz16(r);
+            int gn = n0 + r;
             gn = gn < a.N ? gn : a.N - 1;
             soff[i] = (uint32_t)gn * (uint32_t)a.Kp + c * 16;
+        } else {
+            // 32 rows x 32 B per piece; the two 16-byte halves of a row swap places in rows 8..15 (mod 16)
+            // so that the 8-byte fragment reads of 16 rows x 2 chunks cover all 64 banks once
+            const int r = (p - XP) * 32 + (lane >> 1);
+            const int c = (lane & 1) ^ ((r >> 3) & 1);
+            int gn = n0 + r;
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)(a.Kp >> 1) + c * 16;
         }
     }
     const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
@@ -551,7 +567,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
         for (int i = 0; i < PPW; ++i) {
             const int p = wave + i * NW;
             if (PIECES % NW == 0 || p < PIECES) {
-                const uint8_t* g = (p < BM / 16 ? xbase : a.wq) + soff[i] + kt * BK;
+                const uint8_t* g = p < XP ? xbase + soff[i] + kt * BK : a.wq + soff[i] + kt * WROW;
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
                                                  (void __attribute__((address_space(3)))*)(smem + stage * STAGE + p * 1024),
                                                  16, 0, 0);
@@ -584,16 +600,28 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
     const int frow = lane & 15, fc = lane >> 4;
     const int fsw = (fc ^ swz16(frow)) * 16;
     const int xfrag = (wm * WTM + frow) * BK + fsw;
-    const int wfrag = BM * BK + (wn * WTN + frow) * BK + fsw;
+    const int wfrag = W4 ? BM * BK + (wn * WTN + frow) * 32 + (((fc >> 1) ^ ((frow >> 3) & 1)) * 16) + (fc & 1) * 8
+                         : BM * BK + (wn * WTN + frow) * BK + fsw;
+    static_assert(!W4 || WTN % 16 == 0, "row parity of the W4 swizzle is taken from the fragment row");
+    using WRaw = typename std::conditional<W4, int2v, int4v>::type;   // W4: 16 codes = 8 packed bytes per lane
     auto ldx = [&](int stage, int i) { return *reinterpret_cast<const int4v*>(smem + stage * STAGE + xfrag + i * 16 * BK); };
-    auto ldw = [&](int stage, int j) { return *reinterpret_cast<const int4v*>(smem + stage * STAGE + wfrag + j * 16 * BK); };
+    auto ldw = [&](int stage, int j) { return *reinterpret_cast<const WRaw*>(smem + stage * STAGE + wfrag + j * 16 * WROW); };
+    auto wop = [&](const WRaw& r) -> int4v {
+        if constexpr (W4) {
+            return int4v{r[0] & 0x0F0F0F0F, (int)(((uint32_t)r[0] >> 4) & 0x0F0F0F0Fu), r[1] & 0x0F0F0F0F,
+                         (int)(((uint32_t)r[1] >> 4) & 0x0F0F0F0Fu)};
+        } else {
+            return r;
+        }
+    };
 
     const int nkt = a.Kp / BK;                        // Kp % 128 == 0  ->  nkt is even and >= 2
     issue(0, 0);
     issue(1, 1);
     if (NSTAGE == 4 && nkt > 2) issue(2, 2);
     wait_and_barrier(NSTAGE == 4 ? (nkt > 2 ? 2 : 1) : 0);   // stage 0 landed (NSTAGE 3: stages 0 and 1)
-    int4v xa[TM], xb[TM], w[3];
+    int4v xa[TM], xb[TM];
+    WRaw w[3];
 #pragma unroll
     for (int i = 0; i < TM; ++i) xa[i] = ldx(0, i);
     w[0] = ldw(0, 0);
@@ -620,8 +648,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
             else if (more) w[(j + 2) % 3] = ldw(nxt, j + 2 - TN);                                          \
             if (more && j == TN - 2) { XN[0] = ldx(nxt, 0); XN[1] = ldx(nxt, 1); }                         \
             if (more && j == TN - 1) { XN[2] = ldx(nxt, 2); XN[3] = ldx(nxt, 3); }                         \
+            const int4v wv_ = wop(w[j % 3]);                                                               \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
-                acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[j % 3], X[i], acc[j][i], 0, 0, 0);     \
+                acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv_, X[i], acc[j][i], 0, 0, 0);          \
             if (j >= TN - 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                            \
             else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
@@ -740,15 +769,15 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER, bool W4>
 static int launch_gemm_pipe_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
-    constexpr size_t RING = NSTAGE * (size_t)(BM + BN) * 64;
+    constexpr size_t RING = NSTAGE * ((size_t)BM * 64 + (size_t)BN * (W4 ? 32 : 64));
     constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4;
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    auto k = gemm_i8_pipe_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, STAGGER>;
+    auto k = gemm_i8_pipe_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, STAGGER, W4>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
     if (e != hipSuccess) {
@@ -759,14 +788,14 @@ static int launch_gemm_pipe_e(const GemmArgs& a, hipStream_t st) {
     return vq_check_launch();
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool STAGGER>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool STAGGER, bool W4 = false>
 static int launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
     switch (a.epilogue) {
-        case VQ_EPI_NONE: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, NSTAGE, STAGGER>(a, st);
-        case VQ_EPI_GELU: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, NSTAGE, STAGGER>(a, st);
+        case VQ_EPI_NONE: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, NSTAGE, STAGGER, W4>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, NSTAGE, STAGGER, W4>(a, st);
         case VQ_EPI_GATE_RESID:
-            return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, NSTAGE, STAGGER>(a, st);
-        default: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, NSTAGE, STAGGER>(a, st);
+            return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, NSTAGE, STAGGER, W4>(a, st);
+        default: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, NSTAGE, STAGGER, W4>(a, st);
     }
 }
 
@@ -846,7 +875,7 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
             if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
             return launch_gemm_pipe<256, 288, 4, 2, 4, false>(a, st);
         case 10:  // 4-stage ring + staggered wave halves (DMA issue of one half under the MFMAs of the other)
-            if (w_bits <= 4) return launch_gemm<256, 288, 128, 8, 1>(a, w_bits, st);
+            if (w_bits <= 4) return launch_gemm_pipe<256, 288, 4, 2, 4, true, true>(a, st);
             return launch_gemm_pipe<256, 288, 4, 2, 4, true>(a, st);
         default:
             return VQ_EUNSUP;

@@ -10,6 +10,7 @@ typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8;
 typedef __attribute__((ext_vector_type(4))) _Float16 half4;
 typedef __attribute__((ext_vector_type(4))) int int4v;
+typedef __attribute__((ext_vector_type(2))) int int2v;
 typedef __attribute__((ext_vector_type(16))) int int16v;
 typedef __attribute__((ext_vector_type(4))) float float4v;
 typedef __attribute__((ext_vector_type(16))) float float16v;
