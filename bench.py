@@ -169,7 +169,7 @@ def main():
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)
         tot_ops = sum(o for _, _, o, _ in timing)
         ach = tot_ops / (tot_ms * 1e-3)
-        roof = {"bound": "mfma", "kernel": "gemm_i8_pipe_kernel<256,288,4,2,EPI,4,stagger> (W8A8 Linear: int8 MFMA 16x16x64, LDS-DMA ring, fused dequant epilogue)",
+        roof = {"bound": "mfma", "kernel": "gemm_i8_wide_kernel<256,288,4,2,EPI,stagger> (W8A8 Linear: int8 MFMA 16x16x64, full-line LDS-DMA double buffer, fused dequant epilogue)",
                 "achieved": ach / 1e12, "peak": PEAK_INT8 / 1e12, "unit": "TFLOP/s", "frac": ach / PEAK_INT8,
                 "traffic": None, "launches": len(timing), "avg_launch_us": tot_ms * 1e3 / len(timing),
                 "gemm_time_share_of_step": tot_ms * 1e-3 / el,

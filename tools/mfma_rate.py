@@ -7,7 +7,8 @@ out = torch.zeros(512, dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 iters, blocks = 2000, 256
 for mode, name in [(0, "36x mfma16x16x64"), (1, "+13 ds_read_b128"), (2, "+barrier"), (3, "+reads+barrier"),
-                   (4, "18x mfma32x32x32"), (5, "32x32 +reads"), (7, "32x32 +reads+barrier")]:
+                   (4, "18x mfma32x32x32"), (5, "32x32 +reads"), (7, "32x32 +reads+barrier"),
+                   (9, "reads | sched_barrier | mfma"), (11, "same + barrier"), (22, "asm: reads+mfma all VGPR"), (20, "asm: frags in AGPR"), (21, "asm: acc in AGPR")]:
     for _ in range(2):
         lib.vq_probe_mfma_rate(mode, iters, blocks, out.data_ptr(), st)
     torch.cuda.synchronize()

@@ -8,9 +8,16 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libviditq_hip.so")
 SOURCES = ["api.hip", "rowquant.hip", "rowquant_fast.hip", "pack.hip", "gemm_i8.hip", "attention.hip", "sampler.hip", "probe.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         # keep MFMA accumulators in VGPRs: the AGPR form costs a v_accvgpr_read/write per softmax / epilogue operand
-         "-mllvm", "-amdgpu-mfma-vgpr-form"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# sources whose MFMA accumulators stay in VGPRs: the AGPR form costs a v_accvgpr_read/write per softmax /
+# epilogue operand (attention).  VQ_VGPR_FORM="a.hip,b.hip" overrides the set for experiments.
+VGPR_FORM = {"attention.hip", "gemm_i8.hip", "probe.hip"}
+
+
+def _flags(src: str):
+    env = os.environ.get("VQ_VGPR_FORM")
+    vg = set(env.split(",")) if env is not None else VGPR_FORM
+    return FLAGS + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if src in vg else [])
 
 
 def _hipcc() -> str:
@@ -46,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, "vq_common.h"))):
             procs.append((src, obj, None))
             continue
-        cmd = [hipcc, *FLAGS, "-c", sp, "-o", obj]
+        cmd = [hipcc, *_flags(src), "-c", sp, "-o", obj]
         if verbose:
             print("[viditq build]", " ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

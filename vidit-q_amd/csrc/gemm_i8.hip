@@ -494,6 +494,113 @@ static int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
 //     earlier) has landed and every wave has issued its last read of stage kt-1, so the same point
 //     re-issues DMA(kt+2) into that stage; the vmcnt(0) of the barrier only ever waits for a transfer
 //     that had a whole tile of MFMAs to complete.
+// Shared epilogue of the LDS-DMA ring kernels (called after a workgroup barrier; uses all of smem).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
+                                              int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int frow = lane & 15, fc = lane >> 4;
+    // ---- epilogue: dequantise in the MFMA layout, transpose through LDS, store whole row runs ----
+    // The v2 epilogue stored 8 bytes per lane (16 rows x 32 B per instruction) and reached 2.9 TB/s of
+    // output; a plain fill of the same buffer runs at 5-6.4 TB/s (tools/write_bw.py).  Here every wave
+    // parks its 64 x WTN fp16 sub-tile in its own LDS slab (row stride ROWB), then re-reads it as 16-byte
+    // chunks in row-major order, so one store instruction covers contiguous WTN*2-byte runs of ~3.5 rows;
+    // the residual / gate operands of the fused adds are read with the same coalesced pattern.
+    constexpr int ROWB = WTN * 2 + 16;                // slab row stride in bytes (16 B aligned; 2-way write conflicts)
+    constexpr int SLAB = WTM * ROWB;
+    constexpr int PAR_OFF = NW * SLAB;                // per-channel parameter block behind the slabs
+    float* l_sw = reinterpret_cast<float*>(smem + PAR_OFF);
+    int* l_zw = reinterpret_cast<int*>(smem + PAR_OFF) + BN;
+    int* l_cs = reinterpret_cast<int*>(smem + PAR_OFF) + 2 * BN;
+    float* l_b = reinterpret_cast<float*>(smem + PAR_OFF) + 3 * BN;
+    for (int c = tid; c < BN; c += NT) {
+        const int gn = n0 + c;
+        const bool ok = gn < a.N;
+        l_sw[c] = ok ? a.sw[gn] : 0.f;
+        l_zw[c] = ok ? a.zw[gn] : 0;
+        l_cs[c] = ok ? a.cs[gn] : 0;
+        l_b[c] = (ok && a.bias) ? a.bias[gn] : 0.f;
+    }
+    __syncthreads();
+    uint8_t* slab = smem + wave * SLAB;
+    {
+        float sxm[TM];
+        int zxm[TM], Rm[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + frow;
+            const int mc = m < a.M ? m : a.M - 1;
+            sxm[i] = a.sx[mc];
+            zxm[i] = a.zx[mc];
+            Rm[i] = a.R[mc];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * WTN + j * 16 + 4 * fc;
+            const float4v fsw_ = *reinterpret_cast<const float4v*>(l_sw + nl);
+            const int4v izw = *reinterpret_cast<const int4v*>(l_zw + nl);
+            const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
+            const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tt = acc[j][i][e] - __mul24(izw[e], Rm[i]) - __mul24(zxm[i], ics[e]);
+                    float y = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
+                    if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
+                    o[e] = (half_t)y;
+                }
+                *reinterpret_cast<half4*>(slab + (i * 16 + frow) * ROWB + (j * 16 + 4 * fc) * 2) = o;
+            }
+        }
+    }
+    // second pass: this wave's slab, row-major 16-byte chunks (same wave wrote it: LDS ops are in order)
+    constexpr int CPR = WTN / 8;                      // 16-byte chunks per slab row
+    constexpr int NCH = WTM * CPR;
+    const int mrow0 = m0 + wm * WTM, ncol0 = n0 + wn * WTN;
+#pragma unroll 2
+    for (int c = lane; c < NCH; c += 64) {
+        const int row = c / CPR, col = (c % CPR) * 8;
+        const int m = mrow0 + row, n = ncol0 + col;
+        if (m >= a.M || n >= a.N) continue;
+        half8 y = *reinterpret_cast<const half8*>(slab + row * ROWB + col * 2);
+        const size_t off = (size_t)m * a.ldo + n;
+        const bool full = n + 8 <= a.N;               // N % 4 == 0: otherwise exactly 4 valid
+        if constexpr (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID) {
+            half8 rr;
+            if (full) rr = *reinterpret_cast<const half8*>(a.resid + off);
+            else {
+                const half4 r4 = *reinterpret_cast<const half4*>(a.resid + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rr[e] = r4[e]; rr[4 + e] = (half_t)0.f; }
+            }
+            if constexpr (EPI == VQ_EPI_GATE_RESID) {
+                const float* g = a.gate + (size_t)(m / a.rows_per_gate) * a.N + n;
+                const float4v g0 = *reinterpret_cast<const float4v*>(g);
+                const float4v g1 = full ? *reinterpret_cast<const float4v*>(g + 4) : float4v{0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)rr[e] + (e < 4 ? g0[e] : g1[e - 4]) * (float)y[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)rr[e] + (float)y[e]);
+            }
+        }
+        if (full) *reinterpret_cast<half8*>(a.out + off) = y;
+        else {
+            half4 y4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y4[e] = y[e];
+            *reinterpret_cast<half4*>(a.out + off) = y4;
+        }
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER, bool W4>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(GemmArgs a) {
     // NSTAGE == 3: one DMA batch in flight (plain __syncthreads, vmcnt(0)).
@@ -673,100 +780,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
 #undef VQ_PIPE_TILE
     __syncthreads();
 
-    // ---- epilogue: dequantise in the MFMA layout, transpose through LDS, store whole row runs ----
-    // The v2 epilogue stored 8 bytes per lane (16 rows x 32 B per instruction) and reached 2.9 TB/s of
-    // output; a plain fill of the same buffer runs at 5-6.4 TB/s (tools/write_bw.py).  Here every wave
-    // parks its 64 x WTN fp16 sub-tile in its own LDS slab (row stride ROWB), then re-reads it as 16-byte
-    // chunks in row-major order, so one store instruction covers contiguous WTN*2-byte runs of ~3.5 rows;
-    // the residual / gate operands of the fused adds are read with the same coalesced pattern.
-    constexpr int ROWB = WTN * 2 + 16;                // slab row stride in bytes (16 B aligned; 2-way write conflicts)
-    constexpr int SLAB = WTM * ROWB;
-    constexpr int PAR_OFF = NW * SLAB;                // per-channel parameter block behind the slabs
-    float* l_sw = reinterpret_cast<float*>(smem + PAR_OFF);
-    int* l_zw = reinterpret_cast<int*>(smem + PAR_OFF) + BN;
-    int* l_cs = reinterpret_cast<int*>(smem + PAR_OFF) + 2 * BN;
-    float* l_b = reinterpret_cast<float*>(smem + PAR_OFF) + 3 * BN;
-    for (int c = tid; c < BN; c += NT) {
-        const int gn = n0 + c;
-        const bool ok = gn < a.N;
-        l_sw[c] = ok ? a.sw[gn] : 0.f;
-        l_zw[c] = ok ? a.zw[gn] : 0;
-        l_cs[c] = ok ? a.cs[gn] : 0;
-        l_b[c] = (ok && a.bias) ? a.bias[gn] : 0.f;
-    }
-    __syncthreads();
-    uint8_t* slab = smem + wave * SLAB;
-    {
-        float sxm[TM];
-        int zxm[TM], Rm[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + frow;
-            const int mc = m < a.M ? m : a.M - 1;
-            sxm[i] = a.sx[mc];
-            zxm[i] = a.zx[mc];
-            Rm[i] = a.R[mc];
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = wn * WTN + j * 16 + 4 * fc;
-            const float4v fsw_ = *reinterpret_cast<const float4v*>(l_sw + nl);
-            const int4v izw = *reinterpret_cast<const int4v*>(l_zw + nl);
-            const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
-            const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                half4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int tt = acc[j][i][e] - __mul24(izw[e], Rm[i]) - __mul24(zxm[i], ics[e]);
-                    float y = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
-                    if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
-                    o[e] = (half_t)y;
-                }
-                *reinterpret_cast<half4*>(slab + (i * 16 + frow) * ROWB + (j * 16 + 4 * fc) * 2) = o;
-            }
-        }
-    }
-    // second pass: this wave's slab, row-major 16-byte chunks (same wave wrote it: LDS ops are in order)
-    constexpr int CPR = WTN / 8;                      // 16-byte chunks per slab row
-    constexpr int NCH = WTM * CPR;
-    const int mrow0 = m0 + wm * WTM, ncol0 = n0 + wn * WTN;
-#pragma unroll 2
-    for (int c = lane; c < NCH; c += 64) {
-        const int row = c / CPR, col = (c % CPR) * 8;
-        const int m = mrow0 + row, n = ncol0 + col;
-        if (m >= a.M || n >= a.N) continue;
-        half8 y = *reinterpret_cast<const half8*>(slab + row * ROWB + col * 2);
-        const size_t off = (size_t)m * a.ldo + n;
-        const bool full = n + 8 <= a.N;               // N % 4 == 0: otherwise exactly 4 valid
-        if constexpr (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID) {
-            half8 rr;
-            if (full) rr = *reinterpret_cast<const half8*>(a.resid + off);
-            else {
-                const half4 r4 = *reinterpret_cast<const half4*>(a.resid + off);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { rr[e] = r4[e]; rr[4 + e] = (half_t)0.f; }
-            }
-            if constexpr (EPI == VQ_EPI_GATE_RESID) {
-                const float* g = a.gate + (size_t)(m / a.rows_per_gate) * a.N + n;
-                const float4v g0 = *reinterpret_cast<const float4v*>(g);
-                const float4v g1 = full ? *reinterpret_cast<const float4v*>(g + 4) : float4v{0, 0, 0, 0};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)rr[e] + (e < 4 ? g0[e] : g1[e - 4]) * (float)y[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)rr[e] + (float)y[e]);
-            }
-        }
-        if (full) *reinterpret_cast<half8*>(a.out + off) = y;
-        else {
-            half4 y4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y4[e] = y[e];
-            *reinterpret_cast<half4*>(a.out + off) = y4;
-        }
-    }
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER, bool W4>
@@ -796,6 +810,410 @@ static int launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
         case VQ_EPI_GATE_RESID:
             return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, NSTAGE, STAGGER, W4>(a, st);
         default: return launch_gemm_pipe_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, NSTAGE, STAGGER, W4>(a, st);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Full-line ring kernel (variant 11).  tools/dma_depth.py: the L2 -> LDS fill rate of a CU is bound by
+// cache-line REQUESTS, not bytes: 64-byte row chunks (BK 64) stream at 65 GB/s per CU, 128-byte
+// chunks (one whole line per row) at 127 GB/s.  A 256 x 288 tile at full MFMA rate consumes 63 GB/s,
+// so the BK-64 ring ran AT its fill limit.  Here a stage holds 128 bytes of k per row (two MFMA
+// k-steps), every DMA lane group fetches whole lines, and the ring is a plain double buffer (2 x 68 KiB):
+//   tile kt:  step h=0 | step h=1 ... [j = TN-2: vmcnt(0) + barrier -> DMA(kt+1) landed, stage kt free]
+//   DMA(kt+2) into the freed stage is issued by waves 0..NW/2-1 right after that barrier and by their
+//   SIMD partners NW/2.. a few MFMA groups into the next tile (an LDS-DMA issue blocks the issuing wave
+//   for ~100 cycles; staggering keeps one partner on the MFMA pipe).
+// LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row >> 1) & 7 (W4: 64 B rows, (row >> 2) & 3).
+// ---------------------------------------------------------------------------
+// ABL (profiling only, results wrong): 1 no DMA after the prologue, 2 no MFMA, 4 no barrier, 8 no fragment reads
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(GemmArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int WROW = W4 ? 64 : 128;               // bytes per weight row and stage
+    constexpr int XP = BM / 8, WP = BN * WROW / 1024; // 1 KiB DMA pieces
+    constexpr int STAGE = BM * 128 + BN * WROW;
+    constexpr int PIECES = XP + WP;
+    constexpr int PPW = (PIECES + NW - 1) / NW;
+    constexpr int PLAST = PIECES - (PPW - 1) * NW;
+    constexpr int BARJ = TN - 2;                      // after the last fragment read of the current stage
+    constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (next tile)
+    static_assert(TM == 4 && TN >= 3 && TN % 3 == 0, "fragment rings below");
+    static_assert(BN * WROW % 1024 == 0 && STAGE % 128 == 0, "whole pieces, 128-byte aligned stages");
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    const int T = MT * NTl;
+    const int bid = blockIdx.x;
+    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const bool full_wave = (PIECES % NW == 0) || wave < PLAST;
+    const bool late = STAGGER && wave >= NW / 2;      // wave-uniform
+
+    uint32_t soff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + i * NW;
+        if (p < XP) {
+            const int r = p * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gm = m0 + r;
+            gm = gm < a.M ? gm : a.M - 1;
+            soff[i] = (uint32_t)gm * (uint32_t)a.Kp + c * 16;
+        } else if (!W4) {
+            const int r = (p - XP) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gn = n0 + r;
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)a.Kp + c * 16;
+        } else {
+            const int r = (p - XP) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((r >> 2) & 3);
+            int gn = n0 + r;
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)(a.Kp >> 1) + c * 16;
+        }
+    }
+    const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
+    auto issue = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + i * NW;
+            if (PIECES % NW == 0 || p < PIECES) {
+                const uint8_t* g = p < XP ? xbase + soff[i] + kt * 128 : a.wq + soff[i] + kt * WROW;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                                 (void __attribute__((address_space(3)))*)(smem + stage * STAGE + p * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    int4v acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
+
+    const int frow = lane & 15, fc = lane >> 4;
+    // k-step h (0/1) of a stage = chunks 4h..4h+3 of the 128-byte row: the swizzled address of step 1 is
+    // the address of step 0 with bit 6 flipped (W4: 8-byte reads of a 64-byte row, bit 5)
+    const int xf0 = (wm * WTM + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int wf0 = W4 ? BM * 128 + (wn * WTN + frow) * 64 + (((fc >> 1) ^ ((frow >> 2) & 3)) * 16) + (fc & 1) * 8
+                       : BM * 128 + (wn * WTN + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int xf1 = xf0 ^ 64, wf1 = wf0 ^ (W4 ? 32 : 64);
+    using WRaw = typename std::conditional<W4, int2v, int4v>::type;
+    auto ldx = [&](int stage, int h, int i) {
+        return *reinterpret_cast<const int4v*>(smem + stage * STAGE + (h ? xf1 : xf0) + i * 16 * 128);
+    };
+    auto ldw = [&](int stage, int h, int j) {
+        return *reinterpret_cast<const WRaw*>(smem + stage * STAGE + (h ? wf1 : wf0) + j * 16 * WROW);
+    };
+    auto wop = [&](const WRaw& r) -> int4v {
+        if constexpr (W4) {
+            return int4v{r[0] & 0x0F0F0F0F, (int)(((uint32_t)r[0] >> 4) & 0x0F0F0F0Fu), r[1] & 0x0F0F0F0F,
+                         (int)(((uint32_t)r[1] >> 4) & 0x0F0F0F0Fu)};
+        } else {
+            return r;
+        }
+    };
+
+    const int nkt = a.Kp / 128;
+    issue(0, 0);
+    if (nkt > 1) {
+        issue(1, 1);
+        if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int4v xa[TM], xb[TM];
+    WRaw w[3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xa[i] = ldx(0, 0, i);
+    w[0] = ldw(0, 0, 0);
+    w[1] = ldw(0, 0, 1);
+
+#define VQ_WIDE_STEP(X, XN, H)                                                                             \
+    {                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+            if (H == 1 && j == BARJ && more) {                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+                if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                              \
+                if (!(ABL & 1) && !late && kt + 2 < nkt) issue(cur, kt + 2);                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (!(ABL & 1) && H == 0 && j == DMA_B && late && kt >= 1 && more) {                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                issue(nxt, kt + 1);                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (ABL & 8) {                                                                                 \
+            } else if (j + 2 < TN) w[(j + 2) % 3] = ldw(cur, H, j + 2);                                    \
+            else if (H == 0) w[(j + 2) % 3] = ldw(cur, 1, j + 2 - TN);                                     \
+            else if (more) w[(j + 2) % 3] = ldw(nxt, 0, j + 2 - TN);                                       \
+            if (!(ABL & 8) && (H == 0 || more)) {                                                                          \
+                if (j == TN - 2) { XN[0] = ldx(H == 0 ? cur : nxt, 1 - H, 0); XN[1] = ldx(H == 0 ? cur : nxt, 1 - H, 1); } \
+                if (j == TN - 1) { XN[2] = ldx(H == 0 ? cur : nxt, 1 - H, 2); XN[3] = ldx(H == 0 ? cur : nxt, 1 - H, 3); } \
+            }                                                                                              \
+            const int4v wv_ = wop(w[j % 3]);                                                               \
+            if (ABL & 2) {                                                                                 \
+                asm volatile("" ::"v"(wv_), "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]));                   \
+            } else {                                                                                       \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+                    acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv_, X[i], acc[j][i], 0, 0, 0);      \
+            }                                                                                              \
+            if (j >= TN - 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                            \
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
+        }                                                                                                  \
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1, nxt = cur ^ 1;
+        const bool more = kt + 1 < nkt;
+        VQ_WIDE_STEP(xa, xb, 0)
+        VQ_WIDE_STEP(xb, xa, 1)
+    }
+#undef VQ_WIDE_STEP
+    __syncthreads();
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
+static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4;
+    constexpr size_t LDS = RING > EPIL ? RING : EPIL;
+    static_assert(LDS <= 163840, "LDS budget of one CU");
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    auto k = gemm_i8_wide_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4>;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3(MT * NTl), dim3(NT), LDS, st, a);
+    return vq_check_launch();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STAGGER, bool W4 = false>
+static int launch_gemm_wide(const GemmArgs& a, hipStream_t st) {
+    switch (a.epilogue) {
+        case VQ_EPI_NONE: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, STAGGER, W4>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, STAGGER, W4>(a, st);
+        case VQ_EPI_GATE_RESID:
+            return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, STAGGER, W4>(a, st);
+        default: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, STAGGER, W4>(a, st);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Ping-pong kernel (variant 13).  tools/mfma_rate.py: a fragment read placed BETWEEN MFMAs costs the
+// in-order wave ~14 matrix-pipe cycles (36 MFMA + 13 ds_read_b128 interleaved: 0.71 us per k-step),
+// while the same reads issued as ONE burst ahead of 36 back-to-back MFMAs cost nothing (0.53 us, the
+// bare MFMA rate) because the SIMD partner wave owns the pipe meanwhile.  So the k-step is split into
+// two barrier-separated segments and the two waves of a SIMD (w, w + NW/2) alternate roles:
+//     segment 2s    : waves A  MFMA(step s)                 | waves B  DMA issue + fragment reads(step s)
+//     segment 2s + 1: waves A  DMA issue + reads(step s + 1) | waves B  MFMA(step s)
+// A wave holds ONE fragment set (4 token + 9 channel fragments); nothing but MFMAs is issued in a
+// compute segment.  Stages are full-line (128 B of k per row, 2 steps), double buffered:
+//   stage T is read in segments 4T-1 .. 4T+2, refilled with tile T+2 in segments 4T+3 (A's pieces) and
+//   4T+4 (B's pieces), and every wave drains its DMA (vmcnt(0)) before the barrier that ends segment 4T+6.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pp_kernel(GemmArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int WROW = W4 ? 64 : 128;
+    constexpr int XP = BM / 8, WP = BN * WROW / 1024;
+    constexpr int STAGE = BM * 128 + BN * WROW;
+    constexpr int PIECES = XP + WP;
+    constexpr int PPW = (PIECES + NW - 1) / NW;
+    static_assert(BN * WROW % 1024 == 0 && STAGE % 128 == 0, "whole pieces, 128-byte aligned stages");
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0 && NW % 2 == 0, "tiling");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    const int T = MT * NTl;
+    const int bid = blockIdx.x;
+    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // SIMD partners are waves w and w + NW/2: the partner computes the SAME (wm, wn) sub-tile rows shifted
+    // by half the waves, so the A / B halves are simply the first and second half of the wave index
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const bool late = wave >= NW / 2;                 // wave-uniform: group B
+
+    uint32_t soff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + i * NW;
+        if (p < XP) {
+            const int r = p * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gm = m0 + r;
+            gm = gm < a.M ? gm : a.M - 1;
+            soff[i] = (uint32_t)gm * (uint32_t)a.Kp + c * 16;
+        } else if (!W4) {
+            const int r = (p - XP) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gn = n0 + r;
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)a.Kp + c * 16;
+        } else {
+            const int r = (p - XP) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((r >> 2) & 3);
+            int gn = n0 + r;
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)(a.Kp >> 1) + c * 16;
+        }
+    }
+    const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
+    auto issue = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + i * NW;
+            if (PIECES % NW == 0 || p < PIECES) {
+                const uint8_t* g = p < XP ? xbase + soff[i] + kt * 128 : a.wq + soff[i] + kt * WROW;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                                 (void __attribute__((address_space(3)))*)(smem + stage * STAGE + p * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    int4v acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
+
+    const int frow = lane & 15, fc = lane >> 4;
+    const int xf0 = (wm * WTM + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int wf0 = W4 ? BM * 128 + (wn * WTN + frow) * 64 + (((fc >> 1) ^ ((frow >> 2) & 3)) * 16) + (fc & 1) * 8
+                       : BM * 128 + (wn * WTN + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int xf1 = xf0 ^ 64, wf1 = wf0 ^ (W4 ? 32 : 64);
+    using WRaw = typename std::conditional<W4, int2v, int4v>::type;
+    int4v xf[TM];
+    WRaw wf[TN];
+    auto load_frags = [&](int s) {                    // step s = stage (s >> 1) & 1, half s & 1
+        const uint8_t* st = smem + ((s >> 1) & 1) * STAGE;
+        const uint8_t* px = st + ((s & 1) ? xf1 : xf0);
+        const uint8_t* pw = st + ((s & 1) ? wf1 : wf0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const int4v*>(px + i * 16 * 128);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const WRaw*>(pw + j * 16 * WROW);
+    };
+    auto wop = [&](const WRaw& r) -> int4v {
+        if constexpr (W4) {
+            return int4v{r[0] & 0x0F0F0F0F, (int)(((uint32_t)r[0] >> 4) & 0x0F0F0F0Fu), r[1] & 0x0F0F0F0F,
+                         (int)(((uint32_t)r[1] >> 4) & 0x0F0F0F0Fu)};
+        } else {
+            return r;
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int4v wv = wop(wf[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, xf[i], acc[j][i], 0, 0, 0);
+        }
+    };
+
+    const int nkt = a.Kp / 128, S = 2 * nkt;
+    issue(0, 0);
+    if (nkt > 1) issue(1, 1);
+    // tile 0 must be visible before segment -1 (A's first fragment reads); tile 1 is drained at the end of
+    // segment 2 by the in-loop rule
+    if (nkt > 1) {
+        if ((PIECES % NW == 0) || wave < PIECES - (PPW - 1) * NW) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (!late) {
+        load_frags(0);
+        for (int s = 0; s < S; ++s) {
+            // ---- segment 2s: compute
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            if (s & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- segment 2s + 1: load
+            __builtin_amdgcn_sched_barrier(0);
+            if ((s & 1) && ((s + 3) >> 1) < nkt) issue(((s + 3) >> 1) & 1, (s + 3) >> 1);
+            if (s + 1 < S) load_frags(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the stage can be refilled
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        for (int s = 0; s < S; ++s) {
+            // ---- segment 2s: load
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(s & 1) && s >= 2 && (s >> 1) + 1 < nkt) issue(((s >> 1) + 1) & 1, (s >> 1) + 1);
+            load_frags(s);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- segment 2s + 1: compute
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    __syncthreads();
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4>
+static int launch_gemm_pp_e(const GemmArgs& a, hipStream_t st) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4;
+    constexpr size_t LDS = RING > EPIL ? RING : EPIL;
+    static_assert(LDS <= 163840, "LDS budget of one CU");
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    auto k = gemm_i8_pp_kernel<BM, BN, WAVES_M, WAVES_N, EPI, W4>;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3(MT * NTl), dim3(NT), LDS, st, a);
+    return vq_check_launch();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool W4 = false>
+static int launch_gemm_pp(const GemmArgs& a, hipStream_t st) {
+    switch (a.epilogue) {
+        case VQ_EPI_NONE: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, W4>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, W4>(a, st);
+        case VQ_EPI_GATE_RESID: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, W4>(a, st);
+        default: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, W4>(a, st);
     }
 }
 
@@ -877,9 +1295,35 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         case 10:  // 4-stage ring + staggered wave halves (DMA issue of one half under the MFMAs of the other)
             if (w_bits <= 4) return launch_gemm_pipe<256, 288, 4, 2, 4, true, true>(a, st);
             return launch_gemm_pipe<256, 288, 4, 2, 4, true>(a, st);
+        case 11:  // full-line double buffer: 128 bytes of k per row and stage, staggered DMA issue
+            if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, true, true>(a, st);
+            return launch_gemm_wide<256, 288, 4, 2, true>(a, st);
+        case 13:  // ping-pong: SIMD partners alternate MFMA-only and load-only segments
+            if (w_bits <= 4) return launch_gemm_pp<256, 288, 4, 2, true>(a, st);
+            return launch_gemm_pp<256, 288, 4, 2>(a, st);
+        case 12:  // same without the stagger (comparison)
+            if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, false, true>(a, st);
+            return launch_gemm_wide<256, 288, 4, 2, false>(a, st);
         default:
-            return VQ_EUNSUP;
+            break;
     }
+    if (variant >= 100 && variant < 116 && w_bits > 4) {   // profiling ablations of variant 11 (wrong results)
+#define VQ_ABL(A)                                                                                               \
+    case 100 + A: {                                                                                             \
+        auto k = gemm_i8_wide_kernel<256, 288, 4, 2, VQ_EPI_NONE, true, false, A>;                              \
+        static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160256);          \
+        (void)e;                                                                                                \
+        hipLaunchKernelGGL(k, dim3(((M + 255) / 256) * ((N + 287) / 288)), dim3(512), 160256, st, a);           \
+        return vq_check_launch();                                                                               \
+    }
+        switch (variant) {
+            VQ_ABL(1) VQ_ABL(2) VQ_ABL(3) VQ_ABL(4) VQ_ABL(5) VQ_ABL(8) VQ_ABL(9) VQ_ABL(10) VQ_ABL(12) VQ_ABL(13)
+            default: break;
+        }
+#undef VQ_ABL
+    }
+    return VQ_EUNSUP;
 }
 
 // ---------------------------------------------------------------------------

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, int* out) {
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const int4v*>(b + i * 1024);
 #pragma unroll
             for (int j = 0; j < 9; ++j) wf[j] = *reinterpret_cast<const int4v*>(b + 16384 + j * 1024);
+            if (MODE & 8) __builtin_amdgcn_sched_barrier(0);   // loads stay in one burst ahead of the MFMAs
         }
         if (MODE & 4) {
             int16v* a16 = reinterpret_cast<int16v*>(acc);
@@ -50,6 +51,54 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, int* out) {
     int x = 0;
 #pragma unroll
     for (int j = 0; j < 36; ++j) x ^= acc[j][0] ^ acc[j][1] ^ acc[j][2] ^ acc[j][3];
+    if (x == 0x7fffffff) out[tid] = x;
+}
+
+// Register-file placement probe: the same 13 ds_read_b128 + 36 MFMA 16x16x64 per iteration, with
+//   RF 0: fragments in AGPRs (ds_read ... a[..]; MFMA srcA/srcB = AGPR), accumulators in VGPRs
+//   RF 1: fragments in VGPRs, accumulators in AGPRs
+//   RF 2: everything in VGPRs, inline asm (control for the asm form itself)
+// Question: is the ~14 MFMA-cycles cost of a fragment read a VGPR port conflict between the LDS return
+// and the MFMA operand traffic?
+template <int RF>
+__global__ __launch_bounds__(512) void mfma_rf_kernel(int iters, int* out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 8192; i += 512) reinterpret_cast<int4v*>(smem)[i] = int4v{i, i + 1, i + 2, i + 3};
+    __syncthreads();
+    int4v acc[36];
+#pragma unroll
+    for (int j = 0; j < 36; ++j) acc[j] = int4v{0, 0, 0, 0};
+    int4v f[13];
+    const uint32_t base = (uint32_t)((lane & 15) * 64 + (lane >> 4) * 16);
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t b = base + (it & 1) * 65536;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            if (RF == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(f[i]) : "v"(b), "i"(i * 1024));
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i]) : "v"(b), "i"(i * 1024));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (RF == 0)
+                    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[j * 4 + i]) : "a"(f[4 + j]), "a"(f[i]));
+                else if (RF == 1)
+                    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[j * 4 + i]) : "v"(f[4 + j]), "v"(f[i]));
+                else
+                    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[j * 4 + i]) : "v"(f[4 + j]), "v"(f[i]));
+            }
+    }
+    int x = 0;
+#pragma unroll
+    for (int j = 0; j < 36; ++j) {
+        int4v v;
+        if (RF == 1) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(acc[j][0]));
+        else v = acc[j];
+        x ^= v[0];
+    }
     if (x == 0x7fffffff) out[tid] = x;
 }
 
@@ -182,6 +231,47 @@ __global__ __launch_bounds__(512) void combo_rate_kernel(const uint8_t* src, int
     if (x == 0x7fffffff) out[tid] = x;
 }
 
+// DMA-depth probe: stream 256 "token" rows + 288 "weight" rows, BKB bytes of k per batch, by LDS-DMA
+// with DEPTH batches in flight (counted vmcnt), no consumer.  Reports how the L2 -> LDS fill rate of a
+// CU depends on bytes in flight and on half-line (64 B) vs full-line (128 B) row chunks.
+template <int BKB, int DEPTH>
+__global__ __launch_bounds__(512) void dma_depth_kernel(const uint8_t* src, int stride, int iters, int* out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int NP = 544 * BKB / 1024, PPW = (NP + 7) / 8, PL = NP - (PPW - 1) * 8;
+    constexpr int RPP = 1024 / BKB, CPR = BKB / 16;      // rows per piece, 16-byte chunks per row
+    constexpr int STG = 544 * BKB, NST = (163840 / STG) < DEPTH + 1 ? (163840 / STG) : DEPTH + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rowbase = (blockIdx.x % 64) * 256;
+    const bool fullw = wave < PL || (NP % 8 == 0);
+    uint32_t soff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + i * 8;
+        const int r = p * RPP + lane / CPR;
+        const int row = r < 256 ? rowbase + r : 16384 + (r - 256);
+        soff[i] = (uint32_t)row * (uint32_t)stride + (lane % CPR) * 16;
+    }
+    for (int it = 0; it < iters; ++it) {
+        const int k = (it % (stride / BKB)) * BKB;
+        uint8_t* stage = smem + (it % NST) * STG;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + i * 8;
+            if (p < NP)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + soff[i] + k),
+                                                 (void __attribute__((address_space(3)))*)(stage + p * 1024), 16, 0, 0);
+        }
+        if (fullw) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((DEPTH - 1) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((DEPTH - 1) * (PPW - 1)) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int x = *reinterpret_cast<const int*>(smem + tid * 4);
+    if (x == 0x7fffffff) out[tid] = x;
+}
+
 extern "C" int vq_probe_stage_rate(int mode, const void* src, int stride, int iters, int blocks, int* out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = 3 * 34816;
@@ -192,6 +282,30 @@ extern "C" int vq_probe_stage_rate(int mode, const void* src, int stride, int it
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         (void)e;                                                                                                \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, st, (const uint8_t*)src, stride, iters, out);       \
+    }
+    if (mode >= 400 && mode < 500) {
+#define DGO(B, D)                                                                                               \
+    {                                                                                                           \
+        auto k = dma_depth_kernel<B, D>;                                                                        \
+        static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 163840);          \
+        (void)e;                                                                                                \
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 163840, st, (const uint8_t*)src, stride, iters, out);    \
+    }
+        switch (mode) {
+            case 411: DGO(64, 1) break;
+            case 412: DGO(64, 2) break;
+            case 413: DGO(64, 3) break;
+            case 421: DGO(128, 1) break;
+            case 422: DGO(128, 2) break;
+            case 441: DGO(32, 1) break;
+            case 442: DGO(32, 2) break;
+            case 444: DGO(32, 4) break;
+            case 446: DGO(32, 6) break;
+            default: return VQ_EUNSUP;
+        }
+#undef DGO
+        return vq_check_launch();
     }
     if (mode == 0) GO(0) else if (mode == 1) GO(1) else if (mode == 2) GO(2)
     else if (mode >= 100) {
@@ -241,6 +355,11 @@ extern "C" int vq_probe_mfma_rate(int mode, int iters, int blocks, int* out, voi
         case 4: GO(4) break;
         case 5: GO(5) break;
         case 7: GO(7) break;
+        case 9: GO(9) break;
+        case 11: GO(11) break;
+        case 20: { auto k = mfma_rf_kernel<0>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, st, iters, out); } break;
+        case 21: { auto k = mfma_rf_kernel<1>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, st, iters, out); } break;
+        case 22: { auto k = mfma_rf_kernel<2>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, st, iters, out); } break;
         default: return VQ_EUNSUP;
     }
 #undef GO

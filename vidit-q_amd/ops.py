@@ -227,10 +227,10 @@ def pack_weight(W: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, n_bits: 
 # When set to a list, every GEMM launch is bracketed by two events recorded on the launch stream and
 # (start, end, int8_ops, algorithmic_bytes) is appended - bench.py's live roofline measurement.
 GEMM_TIMING = None
-# kernel variant used when the caller does not choose: 10 = 4-stage LDS-DMA ring, staggered wave halves,
-# LDS-transposed coalesced epilogue, 256x288 tile (csrc/gemm_i8.hip);
-# nibble-packed (<= 4 bit) weights are routed to the register-staged kernel by the library
-DEFAULT_GEMM_VARIANT = 10
+# kernel variant used when the caller does not choose: 11 = full-line (128 B of k per row) double-buffered
+# LDS-DMA ring, staggered DMA issue, LDS-transposed coalesced epilogue, 256x288 tile (csrc/gemm_i8.hip);
+# nibble-packed (<= 4 bit) weights take the same kernel with 64-byte packed rows
+DEFAULT_GEMM_VARIANT = 11
 
 
 def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
