@@ -33,6 +33,8 @@ class QSpec:
     act_scale: Dict[str, torch.Tensor] = field(default_factory=dict)
     alpha: Optional[Sequence[float]] = None
     timerange: Sequence[Sequence[int]] = ((0, 1000),)
+    # layers whose smooth quant was switched off (set_layer_smooth_quant on the script's FP list)
+    smooth_off: Sequence[str] = ("x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer")
     # weight grids fixed at PTQ: name -> (delta [N,1], zp [N,1]); filled lazily when absent
     w_grid: Dict[str, tuple] = field(default_factory=dict)
 
@@ -48,7 +50,17 @@ def qlinear(sd, name: str, x3: torch.Tensor, spec: QSpec, t_id: int = 0) -> torc
     b = sd.get(name + ".bias")
     b = None if b is None else b.float()
     if _is_fp(name, spec):
-        return F.linear(x3.float(), W, b)
+        xf = x3.float()
+        if name in spec.act_scale and spec.alpha is not None and not any(name.startswith(p) for p in spec.smooth_off):
+            # FP weight + smooth quant still on: QuantLayer folds s into W (quant_layer.py:188-189), the STDiT
+            # attention Linears divide the input only (stdit_quant_layer.py:90,181,298) - as released
+            r = fq.find_interval(spec.timerange, t_id)
+            alpha = spec.alpha[r] if isinstance(spec.alpha, (list, tuple)) else spec.alpha
+            sm = fq.smooth_scale(spec.act_scale[name][r], W, alpha)
+            xf = xf / sm
+            if ".mlp." in name:
+                W = W * sm
+        return F.linear(xf, W, b)
     smooth = None
     if name in spec.act_scale and spec.alpha is not None:
         r = fq.find_interval(spec.timerange, t_id)

@@ -309,6 +309,39 @@ def tiny_stdit(R):
             for bn, bv in bufs.items():
                 if bv is not None:
                     out["qp/%s/%s" % (name, bn)] = bv
+        # timestep-wise mixed precision: the reference's own DDIM loop switching per-layer bit widths and the
+        # FP layer set per "hi-lo" key of the step index (gaussian_diffusion.py:740-759); state restored first
+        qnn.load_bitwidth_config(qnn, {"model.blocks.0.mlp.fc1": 4, "model.blocks.1.attn.q": 4}, "weight")
+        import json
+        names = [n for n, mod in qnn.named_modules() if isinstance(mod, R.QuantLayer) and ".blocks." in n]
+        wcfg = {"3-2": {n: (8 if ".mlp." in n else 4) for n in names},
+                "1-0": {n: (6 if n.endswith("attn.q") else 4) for n in names},
+                "fp_layers": {"3-2": ["attn_temp"], "1-0": ["fc1_"]}}
+        acfg = {"3-2": {n: 8 for n in names}, "1-0": {n: 8 for n in names}}
+        out["mp_weight_cfg_json"] = np.array(json.dumps(wcfg))
+        out["mp_act_cfg_json"] = np.array(json.dumps(acfg))
+        qnn.timestep_wise_mp, qnn.time_mp_config_weight, qnn.time_mp_config_act = True, wcfg, acfg
+        from opensora.schedulers.iddpm import IDDPM, forward_with_cfg  # noqa
+        from functools import partial
+        tmp = tempfile.mkdtemp()
+        os.makedirs(os.path.join(tmp, "t2v", "rebuttal_files"))
+        torch.save(torch.zeros(20), os.path.join(tmp, "t2v", "rebuttal_files", "k_for_each_timestep.pth"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            sch = IDDPM(num_sampling_steps=4, cfg_scale=4.0)
+            z = h(torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(43)))
+            out["mp_ddim_z"] = z
+            yy = torch.cat([y[:1], y[1:2]]) if y.shape[0] >= 2 else torch.cat([y, y * 0])
+            out["mp_ddim_y"] = yy
+            samples = sch.ddim_sample_loop(
+                partial(forward_with_cfg, qnn, cfg_scale=4.0),
+                (2, 4, 4, 8, 8), torch.cat([z, z]), clip_denoised=False, model_kwargs=dict(y=yy, mask=mask),
+                progress=False, device="cpu")
+            out["mp_ddim_final"] = samples[:1]
+            out["mp_ddim_timestep_map"] = np.array(sch.timestep_map)
+        finally:
+            os.chdir(cwd)
     npz("tiny_stdit_w4a8.npz", **out)
 
 
@@ -365,7 +398,8 @@ def main():
         quantizer_kats(R)
         layer_kats(R)
         tiny_stdit(R)
-    tiny_pixart()
+    if "--stdit-only" not in sys.argv:
+        tiny_pixart()
 
 
 if __name__ == "__main__":

@@ -12,6 +12,9 @@ def load_npz(name):
     out = {}
     for k in z.files:
         v = z[k]
+        if v.dtype.kind in "US":              # JSON text (configs) stays a python str
+            out[k] = str(v)
+            continue
         if v.dtype == np.float16:
             v = v.astype(np.float32)
         out[k] = torch.from_numpy(v) if v.dtype != np.float64 else v

@@ -190,6 +190,33 @@ def test_tiny_stdit_w4a8_timerange_and_mixed_precision(dev, ops):
     assert qnn.model.blocks[0].mlp.fc1.packed_weight(1).n_bits == 8
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_timestep_wise_mixed_precision_ddim(dev, ops, graphed):
+    """The reference DDIM loop with timestep_wise_mp: per-key bit widths (4/6/8 on the 4-bit grid) and FP
+    layer set, eager and replayed from per-key HIP graphs."""
+    import json
+    from viditq_amd.t2v import IDDPM
+    g = load_npz("tiny_stdit_w4a8.npz")
+    qnn = _build(g, dev, 4, smooth=dict(alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]]),
+                 mixed_precision=[4, 6, 8])
+    qnn.set_layer_smooth_quant(model=qnn, module_name_list=FP_LAYERS, smooth_quant=False,
+                               smooth_quant_running_stat=False)
+    qnn.timestep_wise_mp = True
+    qnn.time_mp_config_weight = json.loads(g["mp_weight_cfg_json"])
+    qnn.time_mp_config_act = json.loads(g["mp_act_cfg_json"])
+    sch = IDDPM(num_sampling_steps=4, cfg_scale=4.0)
+    assert sch.timestep_map == [int(v) for v in g["mp_ddim_timestep_map"]]
+    z, y, mask = g["mp_ddim_z"].to(dev), g["mp_ddim_y"].half().to(dev), g["mask"].to(dev)
+    seen = []
+    out = sch.ddim_sample_loop(qnn, z, dict(y=y, mask=mask), graphed=graphed,
+                               step_callback=lambda i, x: seen.append(
+                                   (qnn.model.blocks[0].mlp.fc1.weight_quantizer.n_bits,
+                                    qnn.model.blocks[1].attn.q.weight_quantizer.n_bits,
+                                    qnn.model.blocks[0].attn_temp.q.get_quant_state())))
+    assert seen == [(8, 4, (False, False))] * 2 + [(4, 6, (True, True))] * 2
+    assert rel_l2(out.cpu(), g["mp_ddim_final"]) < 2e-2       # 4 steps x 4-bit weights: rounding flips compound
+
+
 def test_ddim_loop_matches_reference_trajectory(dev, ops):
     from viditq_amd.t2v import IDDPM
     g = load_npz("tiny_stdit_w8a8.npz")

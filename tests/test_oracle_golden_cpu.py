@@ -127,6 +127,34 @@ def test_tiny_stdit_w4a8_timerange_and_mixed_precision():
     assert rel_l2(out, g["w4a8_mp_cond_t721"]) < 1e-5
 
 
+def test_tiny_stdit_w4a8_timestep_wise_mp_ddim():
+    """4 DDIM steps of the reference sampler with timestep_wise_mp (gaussian_diffusion.py:740-759): per
+    "hi-lo" key of the step index the per-layer weight bits and the FP layer set change."""
+    import json
+    g = load_npz("tiny_stdit_w4a8.npz")
+    sd = state_dict_of(g)
+    qp = quant_params_of(g)
+    act_scale = {n[:-len(".act_quantizer")]: b["act_scale"] for n, b in qp.items()
+                 if n.endswith(".act_quantizer") and "act_scale" in b and n.startswith("blocks")}
+    spec = sr.QSpec(w_bits=4, act_scale=act_scale, alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]])
+    base_fp = tuple(spec.fp_layers)
+    wcfg = json.loads(g["mp_weight_cfg_json"])
+    names = [n[len("model."):] for n in wcfg["3-2"]]
+    tmap, acp = sr.spaced_schedule(4)
+    assert tmap == [int(v) for v in g["mp_ddim_timestep_map"]]
+    x, y, mask = g["mp_ddim_z"], g["mp_ddim_y"], g["mask"]
+    for i in (3, 2, 1, 0):
+        key = [k for k in wcfg if k != "fp_layers" and int(k.split("-")[0]) >= i >= int(k.split("-")[1])][0]
+        spec.layer_w_bits = {n[len("model."):]: b for n, b in wcfg[key].items()}
+        pats = wcfg["fp_layers"][key]
+        spec.fp_layers = base_fp + tuple(n for n in names if any(p in n.split(".") for p in pats))
+        t = torch.tensor([tmap[i]])
+        cond = sr.stdit_forward(sd, TINY_CFG, x, t, y[:1], mask, spec)
+        unc = sr.stdit_forward(sd, TINY_CFG, x, t, y[1:], mask, spec)
+        x = sr.cfg_ddim_step(x, cond, unc, acp, i, 4.0)
+    assert rel_l2(x, g["mp_ddim_final"]) < 1e-4
+
+
 def test_tiny_pixart_w8a8():
     from oracle import pixart_ref as pr
     g = load_npz("tiny_pixart_w8a8.npz")

@@ -6,11 +6,12 @@ sequence are static within a smooth-quant time-range, so both forward-samples of
 uncond) are captured ONCE into a HIP graph (``torch.cuda.CUDAGraph`` records the raw
 ``hipLaunchKernelGGL`` calls our C ABI makes on the capturing stream) and replayed with new latent /
 timestep / text-embedding contents copied into the static input buffers.  One graph per time-range
-(the packed weights and smoothing vectors differ between ranges).
+(the packed weights and smoothing vectors differ between ranges) and per mixed-precision key (the
+per-layer bit widths and FP layer set differ between keys, iddpm.TimestepMP).
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict, Hashable, Optional, Tuple
 
 import torch
 
@@ -68,12 +69,12 @@ class StepGraph:
 
 
 class GraphedSampler:
-    """Lazily captures one StepGraph per smooth-quant time-range of ``qnn``."""
+    """Lazily captures one StepGraph per (smooth-quant time-range, mixed-precision key) of ``qnn``."""
 
     def __init__(self, qnn, y_cond, y_uncond, mask, two_streams: bool = True):
         self.qnn, self.yc, self.yu, self.mask = qnn, y_cond, y_uncond, mask
         self.two_streams = two_streams
-        self.graphs: Dict[int, StepGraph] = {}
+        self.graphs: Dict[Tuple[int, Hashable], StepGraph] = {}
 
     def _range_of(self, t_id: int) -> int:
         from .qdiff.models.quant_layer import find_interval
@@ -82,8 +83,10 @@ class GraphedSampler:
                 return find_interval(layer.timerange, t_id)
         return 0
 
-    def forward_pair(self, x, t_id: int):
-        r = self._range_of(t_id)
+    def forward_pair(self, x, t_id: int, mp_key: Hashable = None):
+        """``mp_key``: whatever identifies the current per-layer bit-width / FP-layer state (the caller has
+        already applied it to ``qnn``); a new key captures a new graph."""
+        r = (self._range_of(t_id), mp_key)
         g = self.graphs.get(r)
         if g is None:
             g = self.graphs[r] = StepGraph(self.qnn, x, self.yc, self.yu, self.mask, t_id,

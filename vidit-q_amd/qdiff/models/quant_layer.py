@@ -221,6 +221,16 @@ class QuantLayer(nn.Module):
         return ops.rowquant(x3, n_bits=aq.n_bits, s=s, add_rows=add_rows, add_div=add_div,
                             delta=aq.delta.float(), zp=aq.zero_point.float())
 
+    # With weight_quant off and smooth_quant on, QuantLayer multiplies the FP weight by the smoothing vector
+    # (quant_layer.py:188-189: (x/s)(W*s)^T = x W^T); the STDiT attention subclasses do NOT
+    # (stdit_quant_layer.py:90,181,298: (x/s) W^T) - kept as released, see fp_weight_smoothed there.
+    fp_weight_smoothed = True
+
+    def _fp_weight(self, s):
+        if s is None or not self.fp_weight_smoothed:
+            return self.org_weight
+        return (self.org_weight.float() * s).to(self.org_weight.dtype)
+
     # ------------------------------------------------------------------ forward
     def forward(self, input: torch.Tensor, scale: float = 1.0, split: int = 0, smooth_quant_enable: bool = False):
         if split != 0:
@@ -236,7 +246,7 @@ class QuantLayer(nn.Module):
 
         # ---- FP route -------------------------------------------------------------------------
         if not self.weight_quant and not (self.act_quant and not self.disable_act_quant):
-            weight = self.org_weight if s is None else (self.org_weight.float() * s).to(self.org_weight.dtype)
+            weight = self._fp_weight(s)
             x = input if s is None else (input.float() / s).to(input.dtype)
             return self.activation_function(self.fwd_func(x, weight.to(x.dtype), _cast(self.org_bias, x.dtype),
                                                           **self.fwd_kwargs))
@@ -279,7 +289,7 @@ class QuantLayer(nn.Module):
                 weight = self.weight_quantizer(self.weight)
             bias = self.bias
         else:
-            weight = self.org_weight if s is None else (self.org_weight.float() * s).to(self.org_weight.dtype)
+            weight = self._fp_weight(s)
             bias = self.org_bias
         out = self.fwd_func(x, weight.to(x.dtype), _cast(bias, x.dtype), **self.fwd_kwargs)
         return self.activation_function(out)

@@ -7,6 +7,12 @@ so that a "token" is a (t, s) position whose scale is shared over the batch:
   QuantCrossAttnLinear    q: [B, T*S, C] as is; kv: [1, sum_Lp, C] per token when dynamic, or
                           [B, n_prompt, C] for static per-token params      (:198-213,268-281)
 All views are pure reshapes of contiguous memory - no data movement.
+
+As-released behaviour kept: with weight quantization OFF and smooth quant ON these three classes divide
+the input by the smoothing vector but use the un-scaled FP weight (stdit_quant_layer.py:90,181,298), i.e.
+an FP'd attention Linear whose smooth quant was not switched off computes (x/s) W^T.  The shipped
+scripts switch smooth quant off for their FP list, so this only shows when a caller FP's such a layer
+by hand (e.g. an ``fp_layers`` entry of a mixed-precision YAML).
 """
 from __future__ import annotations
 
@@ -16,6 +22,8 @@ from .quant_layer import QuantLayer
 
 
 class QuantSpatialAttnLinear(QuantLayer):
+    fp_weight_smoothed = False
+
     def _token_view(self, input: torch.Tensor) -> torch.Tensor:
         T = self.act_quant_params["n_temporal_token"]
         S = self.act_quant_params["n_spatial_token"]
@@ -25,6 +33,8 @@ class QuantSpatialAttnLinear(QuantLayer):
 
 
 class QuantTemporalAttnLinear(QuantLayer):
+    fp_weight_smoothed = False
+
     def _token_view(self, input: torch.Tensor) -> torch.Tensor:
         T = self.act_quant_params["n_temporal_token"]
         S = self.act_quant_params["n_spatial_token"]
@@ -34,6 +44,8 @@ class QuantTemporalAttnLinear(QuantLayer):
 
 
 class QuantCrossAttnLinear(QuantLayer):
+    fp_weight_smoothed = False
+
     def _token_view(self, input: torch.Tensor) -> torch.Tensor:
         T = self.act_quant_params["n_temporal_token"]
         S = self.act_quant_params["n_spatial_token"]

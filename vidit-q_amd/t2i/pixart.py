@@ -26,7 +26,7 @@ from ..qdiff.models.quant_block import QuantAttention
 from ..qdiff.models.quant_layer import QuantLayer
 from ..qdiff.quantizer.dynamic_quantizer import DynamicActQuantizer
 from ..t2v.stdit import (CaptionEmbedder, Mlp, MultiHeadCrossAttention, T2IFinalLayer, TimestepEmbedder, approx_gelu,
-                         get_1d_sincos_pos_embed_from_grid, t2i_modulate)
+                         get_1d_sincos_pos_embed_from_grid, seq_offsets, t2i_modulate)
 
 
 def get_2d_sincos_pos_embed(embed_dim, grid_size, pe_interpolation=1.0, base_size=16):
@@ -268,7 +268,7 @@ class PixArtMS(nn.Module):
             N = x.shape[1]
             x2 = x.reshape(bs * N, C)
             y2 = y.reshape(-1, C).contiguous()
-            off = torch.tensor(np.concatenate([[0], np.cumsum(y_lens)]), dtype=torch.int32).to(x.device)
+            off = seq_offsets(y_lens, x.device)
             t0c = t0.contiguous()
             for block in self.blocks:
                 block.forward_fused(x2, y2, t0c, off, bs)

@@ -27,6 +27,48 @@ import torch
 from .. import ops
 
 
+def get_key_for_value(dict_ranges, value):
+    """gaussian_diffusion.py:24-29: first "hi-lo" key whose closed range holds ``value`` (keys are walked
+    in file order; a non-range key such as ``fp_layers`` raises exactly as in the reference)."""
+    for key in dict_ranges:
+        range_start, range_end = map(int, key.split("-"))
+        if range_start >= value >= range_end:
+            return key
+    return None
+
+
+class TimestepMP:
+    """Per-step mixed-precision switching of ddim_sample_loop_progressive (gaussian_diffusion.py:740-759).
+
+    Driven by the attributes the reference script sets on the QuantModel (quant_txt2video_mp.py:373,
+    533-540): ``timestep_wise_mp``, ``time_mp_config_weight`` (``{"hi-lo": {layer: bits}, ...,
+    "fp_layers": {"hi-lo": [patterns]}}``) and ``time_mp_config_act``.  The key is looked up with the loop
+    index i (position in the respaced schedule), not the raw timestep."""
+
+    def __init__(self, qnn):
+        self.qnn = qnn
+        self.key_org = None
+        self.fp_layer_list_org = None
+
+    def apply(self, i: int):
+        qnn = self.qnn
+        key = get_key_for_value(qnn.time_mp_config_weight, i)
+        if key is None:
+            raise RuntimeError("this timestep %d is not included by the config" % i)
+        if key != self.key_org:
+            if self.fp_layer_list_org is not None:
+                qnn.set_layer_quant(model=qnn, module_name_list=self.fp_layer_list_org, quant_level="per_layer",
+                                    weight_quant=True, act_quant=True, prefix="")
+            fp_layer_list = qnn.time_mp_config_weight["fp_layers"][key]
+            qnn.set_layer_quant(model=qnn, module_name_list=fp_layer_list, quant_level="per_layer",
+                                weight_quant=False, act_quant=False, prefix="")
+            qnn.load_bitwidth_config(model=qnn, bit_config=qnn.time_mp_config_weight[key], bit_type="weight")
+            qnn.load_bitwidth_config(model=qnn, bit_config=qnn.time_mp_config_act[key], bit_type="act")
+            self.key_org = key
+            self.fp_layer_list_org = fp_layer_list
+        return key
+
+
 def space_timesteps(num_timesteps, section_counts):
     """respace.py:7-56."""
     if isinstance(section_counts, str):
@@ -134,8 +176,10 @@ class IDDPM:
         return self.ddim_sample_loop(model, z, model_args, ks=ks, progress=progress)
 
     @torch.no_grad()
-    def ddim_sample_loop(self, model, z, model_args, ks=None, progress=False, step_callback=None):
-        """x: the kept half only (both halves evolve identically in the reference: :161-162)."""
+    def ddim_sample_loop(self, model, z, model_args, ks=None, progress=False, step_callback=None, graphed=False):
+        """x: the kept half only (both halves evolve identically in the reference: :161-162).
+        ``graphed``: replay the two forward-samples of a step from a HIP graph (one graph per smooth-quant
+        time-range and mixed-precision key, graph.GraphedSampler); needs ``cfg_split`` and a QuantModel."""
         x = z.float().contiguous()
         n = x.shape[0]
         y, mask = model_args["y"], model_args.get("mask")
@@ -144,10 +188,20 @@ class IDDPM:
         y_cond, y_uncond = y[:n], y[n:]
         buf = torch.empty_like(x)
         indices = list(range(self.num_timesteps))[::-1]
+        mp = TimestepMP(model) if getattr(model, "timestep_wise_mp", False) else None
+        gs = None
+        if graphed:
+            from ..graph import GraphedSampler
+            assert cfg_split and _accepts_timestep_id(model) and not extra, "graphed sampling: cfg_split QuantModel"
+            gs = GraphedSampler(model, y_cond, y_uncond, mask)
         for i in indices:
             t_id = self.timestep_map[i]
-            t = torch.full((n,), t_id, device=x.device, dtype=torch.long)
-            cond, uncond = model_forward_pair(model, x, t, y_cond, y_uncond, mask, cfg_split, t_id, extra)
+            key = mp.apply(i) if mp is not None else None
+            if gs is not None:
+                cond, uncond = gs.forward_pair(x, t_id, key)
+            else:
+                t = torch.full((n,), t_id, device=x.device, dtype=torch.long)
+                cond, uncond = model_forward_pair(model, x, t, y_cond, y_uncond, mask, cfg_split, t_id, extra)
             k = 0.0 if ks is None else float(ks[(999 - t_id) // 50])
             out = self.ddim_step(x, cond, uncond, i, self.cfg_scale, k, out=buf)
             x, buf = out, x

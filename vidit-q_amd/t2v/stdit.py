@@ -185,6 +185,21 @@ class Attention(nn.Module):
         return self.proj(o.reshape(Bp, Np, C).to(dt))
 
 
+_OFFSETS = {}
+
+
+def seq_offsets(lens, device) -> torch.Tensor:
+    """int32 prefix sums [0, l0, l0+l1, ...] of the prompt lengths on ``device``; cached per (lengths,
+    device) so that a HIP-graph capture never sees the host-to-device copy."""
+    key = (tuple(int(v) for v in lens), str(device))
+    off = _OFFSETS.get(key)
+    if off is None:
+        if len(_OFFSETS) > 4096:
+            _OFFSETS.clear()
+        off = _OFFSETS[key] = torch.tensor(np.concatenate([[0], np.cumsum(key[0])]), dtype=torch.int32).to(device)
+    return off
+
+
 class MultiHeadCrossAttention(nn.Module):
     """blocks.py:277-310: q from image tokens, k/v from the (mask-selected) prompt tokens."""
 
@@ -203,7 +218,7 @@ class MultiHeadCrossAttention(nn.Module):
         q = self.q_linear(x).reshape(B * N, C).half().contiguous()
         kv = self.kv_linear(cond).reshape(-1, 2 * C).half().contiguous()
         lens = mask if mask is not None else [kv.shape[0] // B] * B
-        off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=x.device)
+        off = seq_offsets(lens, x.device)
         o = self.core.cross(q, kv, off, B, N)
         return self.proj(o.reshape(B, N, C).to(dt))
 
@@ -459,7 +474,7 @@ class STDiT(nn.Module):
                 m = m.reshape(B, -1)
                 idx = torch.nonzero(m.reshape(-1) != 0, as_tuple=False).reshape(-1)
                 lens = [int(v) for v in m.sum(dim=1).tolist()]
-                off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32).to(y.device)
+                off = seq_offsets(lens, y.device)
                 self._mask_cache = (key, idx, lens, off)
             _, idx, lens, off = self._mask_cache
             ysel = y.squeeze(1).reshape(-1, C).index_select(0, idx).reshape(1, -1, C)
@@ -489,7 +504,7 @@ class STDiT(nn.Module):
             x2 = x.reshape(B * self.num_patches, C)
             y2 = y.reshape(-1, C).contiguous()
             if off is None:
-                off = torch.tensor(np.concatenate([[0], np.cumsum(y_lens)]), dtype=torch.int32).to(x.device)
+                off = seq_offsets(y_lens, x.device)
             t0c = t0.contiguous()
             for i, block in enumerate(self.blocks):
                 block.forward_fused(x2, y2, t0c, off, self.pos_embed_temporal if i == 0 else None, B)
