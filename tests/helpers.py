@@ -42,3 +42,15 @@ def rel_l2(a, b):
 
 TINY_CFG = dict(T=4, S=16, H=4, depth=2, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(4, 8, 8))
 FP_LAYERS = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+
+
+def tiny_inputs(n=1, seed=5):
+    """Same draw as tests/golden/make_golden.py::tiny_inputs (fp16-representable values)."""
+    g = torch.Generator().manual_seed(seed)
+    hh = lambda t: t.half().float()   # noqa: E731
+    x = hh(torch.randn(n, 4, 4, 8, 8, generator=g))
+    y = hh(torch.randn(2 * n, 1, 12, 32, generator=g) * 0.5)
+    mask = torch.zeros(n, 12, dtype=torch.int64)
+    for i, L in enumerate([7, 12, 3][:n]):
+        mask[i, :L] = 1
+    return x, y, mask

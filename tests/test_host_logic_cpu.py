@@ -152,3 +152,37 @@ def test_iddpm_schedule_and_cfg_rule_cpu():
     half = unc[:, :3] + 4.0 * (cond[:, :3] - unc[:, :3])                   # guidance on 3 of 4 eps channels (A.4-5)
     assert torch.allclose(out[:1, :3], half) and torch.allclose(out[1:, :3], half)
     assert torch.equal(out[:1, 3:], cond[:, 3:]) and torch.equal(out[1:, 3:], unc[:, 3:])
+
+
+def test_mixed_precision_yaml_and_key_lookup(tmp_path):
+    """The MP YAML surface (configs/quant/opensora/mixed_precision/*.yaml) and get_key_for_value
+    (gaussian_diffusion.py:24-29): closed "hi-lo" ranges walked in file order."""
+    from viditq_amd import ptq
+    from viditq_amd.t2v.iddpm import get_key_for_value
+    p = tmp_path / "mp.yaml"
+    p.write_text("14-10:\n  model.blocks.0.attn.q: 4\n  model.blocks.0.mlp.fc1: 8\n19-15:\n  model.blocks.0.attn.q: 8\n"
+                 "4-0:\n  model.blocks.0.attn.q: 4\n9-5:\n  model.blocks.0.attn.q: 6\n"
+                 "fp_layers:\n  14-10:\n  - fc1_\n  19-15:\n  - fc1_\n  4-0: []\n  9-5:\n  - attn_temp\n")
+    cfg = ptq.load_mp_config(str(p))
+    assert list(cfg) == ["14-10", "19-15", "4-0", "9-5", "fp_layers"]
+    assert cfg["14-10"]["model.blocks.0.mlp.fc1"] == 8 and cfg["fp_layers"]["9-5"] == ["attn_temp"]
+    assert [get_key_for_value(cfg, i) for i in (19, 15, 14, 10, 9, 5, 4, 0)] == \
+        ["19-15", "19-15", "14-10", "14-10", "9-5", "9-5", "4-0", "4-0"]
+    with pytest.raises(ValueError):          # a step outside every range reaches the 'fp_layers' key, as in the reference
+        get_key_for_value(cfg, 20)
+
+
+def test_get_quant_calib_data_selection():
+    """qdiff/utils.py:20-63: n_steps evenly spaced trajectory steps, first 2*n_samples rows of each."""
+    from viditq_amd import ptq
+    from viditq_amd.config import to_config
+    cfg = to_config({"calib_data": {"n_samples": 2, "n_steps": 5, "batch_size": 1}})
+    steps = 20
+    data = {"xs": [torch.full((6, 3), float(i)) for i in range(steps)],
+            "ts": [torch.full((6,), 1000 - 50 * i) for i in range(steps)],
+            "cond_emb": [torch.zeros(6, 1, 4, 8) for _ in range(steps)],
+            "mask": [torch.ones(6, 4, dtype=torch.int64) for _ in range(steps)]}
+    xs, ts, cs, ms = ptq.get_quant_calib_data(cfg, data)
+    assert xs.shape == (5 * 4, 3) and ts.shape == (20,) and cs.shape == (20, 1, 4, 8) and ms.shape == (20, 4)
+    assert ts.reshape(5, 4)[:, 0].tolist() == [1000, 800, 600, 400, 200]
+    assert xs.reshape(5, 4, 3)[:, 0, 0].tolist() == [0.0, 4.0, 8.0, 12.0, 16.0]

@@ -217,6 +217,73 @@ def test_timestep_wise_mixed_precision_ddim(dev, ops, graphed):
     assert rel_l2(out.cpu(), g["mp_ddim_final"]) < 2e-2       # 4 steps x 4-bit weights: rounding flips compound
 
 
+def test_ptq_calibrate_reproduces_reference_quant_params(dev, ops, tmp_path):
+    """ptq.calibrate (the three passes of t2v/scripts/ptq.py:207-362) on the calibration sequence the
+    golden generator replayed through the REFERENCE classes: momentum act scales per time-range and the
+    per-bit-width / per-range weight grids must come out the same; then the ckpt.pth round trip."""
+    import viditq_amd  # noqa
+    from helpers import tiny_inputs
+    from viditq_amd import ptq
+    from viditq_amd.config import to_config
+    from viditq_amd.qdiff.models import QuantModel
+    from viditq_amd.t2v import STDiT
+    g = load_npz("tiny_stdit_w4a8.npz")
+    smooth = dict(alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]])
+
+    def fresh():
+        m = STDiT(dtype=torch.float16, **TINY)
+        m.load_state_dict(state_dict_of(g), strict=True)
+        wq, aq = _cfgs(4, smooth, [4, 6, 8])
+        q = QuantModel(m.half().to(dev).eval(), wq, aq)
+        q.cfg_split = True
+        return q, wq, aq
+    qnn, wq, aq = fresh()
+    cfg = to_config({"calib_data": {"n_samples": 1, "batch_size": 1, "n_steps": 4},
+                     "quant": {"weight": {"quantizer": wq}, "activation": {"quantizer": aq}}})
+    ins = [tiny_inputs(1, seed=20 + i) for i in range(4)]
+    xs = torch.cat([a[0] for a in ins])
+    cs = torch.cat([a[1][:1] for a in ins]).half()
+    masks = torch.cat([a[2] for a in ins])
+    ts = torch.tensor([999, 721, 400, 61])
+    qd = ptq.calibrate(qnn, cfg, (xs, ts, cs, masks), fp_layer_list=FP_LAYERS, samples_per_step=1, batch_size=1)
+    ref = quant_params_of(g)
+    n_checked = 0
+    for name, (bufs, _) in qd.items():
+        if not name.startswith("blocks"):
+            continue
+        for bn in ("act_scale", "delta_list", "zero_point_list", "delta", "zero_point"):
+            if bn in ref.get(name, {}) and bufs.get(bn) is not None:
+                a, b = bufs[bn].float().cpu(), ref[name][bn].float()
+                # fp16 activations on the GPU vs fp32 in the reference: max|x| statistics agree to fp16 rounding;
+                # zero points may move by one code where -min/delta sits on a rounding boundary
+                if "zero_point" in bn:
+                    assert (a.reshape(b.shape) - b).abs().max() <= 1, (name, bn)
+                elif bn == "act_scale":      # max|x| of fp16 activations (attention outputs included)
+                    assert rel_l2(a.reshape(b.shape), b) < 2e-3 and torch.allclose(a.reshape(b.shape), b, rtol=3e-2, atol=1e-4), (name, bn)
+                else:                        # grids of W * act_scale^0.11 / max|W|^0.89
+                    assert torch.allclose(a.reshape(b.shape), b, rtol=4e-3, atol=1e-6), (name, bn)
+                n_checked += 1
+    assert n_checked >= 26 * 3
+    # the calibrated model reproduces the reference outputs like the one loaded from the reference's params
+    x, y, mask = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev)
+    out = qnn(x, torch.tensor([721], device=dev), y[:1], mask=mask)
+    assert rel_l2(out.cpu(), g["w4a8_cond_t721"]) < 2e-2
+    # ckpt.pth schema round trip into a fresh model
+    path = str(tmp_path / "ckpt.pth")
+    ptq.save_quant_params(qnn, path)
+    q2, _, _ = fresh()
+    q2.set_quant_state(True, True)
+    q2.set_smooth_quant(smooth_quant=True, smooth_quant_running_stat=False)
+    q2.set_layer_smooth_quant(model=q2, module_name_list=FP_LAYERS, smooth_quant=False, smooth_quant_running_stat=False)
+    q2.set_layer_quant(model=q2, module_name_list=FP_LAYERS, quant_level="per_layer", weight_quant=False,
+                       act_quant=False, prefix="")
+    q2.set_quant_init_done("weight")
+    q2.set_quant_init_done("activation")
+    ptq.load_quant_params(q2, path)
+    out2 = q2(x, torch.tensor([721], device=dev), y[:1], mask=mask)
+    assert torch.equal(out2, out)
+
+
 def test_ddim_loop_matches_reference_trajectory(dev, ops):
     from viditq_amd.t2v import IDDPM
     g = load_npz("tiny_stdit_w8a8.npz")
