@@ -31,7 +31,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--depth", type=int, default=28, help="STDiT depth (28 = STDiT-XL/2; anything else is a debug run)")
-    ap.add_argument("--plan", default="w8a8", choices=["w8a8"])
+    ap.add_argument("--plan", default="w8a8", choices=["w8a8", "w4a8", "w4a8_mp"],
+                    help="w8a8 = BASELINE metric (w8a8_dynamic.yaml); w4a8 = ViDiT-Q W4A8 timestep-aware channel "
+                         "balancing, synthetic calibration; w4a8_mp = the same with the per-layer mixed-precision "
+                         "config on the 20-step schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=None)
@@ -98,14 +101,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = loads_yaml(synth.W8A8_DYNAMIC)
+    cfg = loads_yaml(synth.W8A8_DYNAMIC if a.plan == "w8a8" else synth.W4A8_TIMESTEP_AWARE)
     with torch.no_grad():
         model = synth.build_stdit(dev, depth=a.depth)
-        qnn = shard.quantize_and_distribute(model, cfg, rank, world)     # rank 0 packs, RCCL broadcast
+        qnn = shard.quantize_and_distribute(model, cfg, rank, world)     # rank 0 calibrates + packs, RCCL broadcast
         if a.gemm_variant is not None:
             ops.DEFAULT_GEMM_VARIANT = a.gemm_variant
         assert all(b.fused_ok() for b in qnn.model.blocks), "hot path must be the fused HIP route"
-        sch = IDDPM(num_sampling_steps=100, cfg_scale=4.0)
+        n_sampling = 20 if a.plan == "w4a8_mp" else 100
+        sch = IDDPM(num_sampling_steps=n_sampling, cfg_scale=4.0)
+        mp = None
+        if a.plan == "w4a8_mp":
+            from viditq_amd import ptq
+            from viditq_amd.t2v.iddpm import TimestepMP
+            ptq.enable_timestep_wise_mp(qnn, *synth.synthetic_mp_config(qnn, n_sampling))
+            mp = TimestepMP(qnn)
         # one prompt per GPU in flight; prompt index = rank (prompt i -> rank i mod R)
         embeds, lens = synth.synthetic_prompts(world, dev)
         x = synth.synthetic_latent(rank, device=dev).float()
@@ -121,8 +131,9 @@ def main():
         def step(j, x, buf, eager=False):
             i = idx[j % len(idx)]
             t_id = sch.timestep_map[i]
+            key = mp.apply(i) if mp is not None else None   # per-layer bit widths of this step's range
             if gs is not None and not eager:            # both forward-samples replayed from one HIP graph
-                cond, unc = gs.forward_pair(x, t_id)
+                cond, unc = gs.forward_pair(x, t_id, key)
             else:
                 t = torch.full((1,), t_id, device=dev, dtype=torch.long)
                 cond = qnn(x, t, y_c, mask=mask, timestep_id=t_id)
@@ -130,6 +141,14 @@ def main():
             out = sch.ddim_step(x, cond, unc, i, sch.cfg_scale, 0.0, out=buf)
             return out, x
 
+        if mp is not None:                              # pack + capture every mixed-precision key up front
+            for i in idx[::max(1, len(idx) // 4)]:
+                key = mp.apply(i)
+                if gs is not None:
+                    gs.forward_pair(x, sch.timestep_map[i], key)
+        elif gs is not None and synth.uses_smooth_quant(cfg):   # one graph per smooth-quant time-range
+            for t_probe in (999, 0):
+                gs.forward_pair(x, t_probe, None)
         for j in range(a.warmup):
             x, buf = step(j, x, buf)
         torch.cuda.synchronize()
@@ -178,13 +197,19 @@ def main():
     if rank == 0:
         steps_total = a.steps * world
         value = steps_total / el_max
-        line = {"metric": "denoising steps/sec (whole node), OpenSORA STDiT 16x512x512 W8A8", "value": value,
+        plan_name = {"w8a8": "W8A8", "w4a8": "W4A8 (timestep-aware channel balancing)",
+                     "w4a8_mp": "W4A8 mixed precision (per-layer bit widths)"}[a.plan]
+        plan_yaml = {"w8a8": "w8a8_dynamic.yaml", "w4a8": "w4a8_timestep_aware_cb.yaml, synthetic calibration",
+                     "w4a8_mp": "w4a8_timestep_aware_cb.yaml + t20 mixed-precision config, synthetic calibration"}[a.plan]
+        line = {"metric": "denoising steps/sec (whole node), OpenSORA STDiT 16x512x512 " + plan_name, "value": value,
                 "unit": "denoising steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": el_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "int8 (W8A8 Linear, int32 acc) + fp16 attention/residual",
+                "vs_baseline": None,
+                "dtype": ("int8 (W8A8 Linear, int32 acc)" if a.plan == "w8a8" else "int8 x int4/int8 weights (W4A8 Linear, int32 acc)")
+                         + " + fp16 attention/residual",
                 "data": "synthetic (random-init STDiT-XL/2 weights, N(0,1) latents, random text embeds)",
-                "config": {"workload": "OpenSORA STDiT-XL/2 16x512x512 W8A8 (w8a8_dynamic.yaml), 1 prompt per GPU, "
-                                       "DDIM-100 schedule, cfg 4.0, cfg_split, depth %d" % a.depth,
+                "config": {"workload": "OpenSORA STDiT-XL/2 16x512x512 %s (%s), 1 prompt per GPU, "
+                                       "DDIM-%d schedule, cfg 4.0, cfg_split, depth %d" % (plan_name, plan_yaml, n_sampling, a.depth),
                            "tokens": 16384, "prompts_in_flight": world, "sharding": "prompt -> rank (no in-step collective)",
                            "status_word": status, "hip_graph": not a.no_graph, "cond_uncond_streams": 1 if (a.one_stream or a.no_graph) else 2},
                 "whole_step_int8_frac": 43.87e12 * (a.depth / 28.0) * value / world / PEAK_INT8,

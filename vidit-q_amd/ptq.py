@@ -34,6 +34,12 @@ def collect_calib_data(qnn: QuantModel, scheduler, z: torch.Tensor, y: torch.Ten
     y [2n, 1, L, Cc] and ``mask`` repeated to 2n rows; lists are ordered first step (t high) first."""
     state = qnn.get_quant_state()
     qnn.set_quant_state(False, False)
+    # plain FP model, as get_calib_data.py runs it: no channel balancing (its statistics do not exist yet)
+    flags = [(layer, layer.smooth_quant, getattr(layer, "smooth_quant_running_stat", False))
+             for _, layer in qnn.quant_layers()]
+    for layer, _, _ in flags:
+        layer.smooth_quant = False
+        layer.smooth_quant_running_stat = False
     data = {"xs": [], "ts": [], "cond_emb": [], "mask": []}
     n = z.shape[0]
     x = z.float()
@@ -53,6 +59,8 @@ def collect_calib_data(qnn: QuantModel, scheduler, z: torch.Tensor, y: torch.Ten
         cond, uncond = model_forward_pair(qnn, x, t, y[:n], y[n:], mask, cfg_split, t_id, {})
         out = scheduler.ddim_step(x, cond, uncond, i, scheduler.cfg_scale, 0.0, out=buf)
         x, buf = out, x
+    for layer, sq, rs in flags:
+        layer.smooth_quant, layer.smooth_quant_running_stat = sq, rs
     qnn.set_quant_state(*state)
     return data
 

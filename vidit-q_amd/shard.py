@@ -140,15 +140,18 @@ def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.R
         qnn = synth.quantize_model(model, cfg, fp_layers)
         prepack(qnn)
         return qnn
-    wq, aq = synth.quant_params_from_config(cfg, T=model.num_temporal, S=model.num_spatial)
-    qnn = QuantModel(model, wq, aq, model_type="opensora")
-    qnn.cfg_split = bool(cfg.get("cfg_split", False))
-    qnn.set_module_name_for_quantizer(qnn.model)
-    qnn.fp_layer_list = list(fp_layers)
+    qnn = synth.wrap_model(model, cfg, fp_layers)
+    smooth = synth.uses_smooth_quant(cfg)
     if rank == 0:
-        synth.init_weight_quantizers(qnn)
-        qnn.set_quant_state(True, True)
+        if smooth:
+            synth.calibrate_synthetic(qnn, cfg, fp_layers)
+            synth.set_inference_state(qnn, cfg, fp_layers)
+        else:
+            synth.init_weight_quantizers(qnn)
+            qnn.set_quant_state(True, True)
         prepack(qnn)
+    elif smooth:
+        synth.set_inference_state(qnn, cfg, fp_layers)
     else:
         qnn.set_quant_init_done("weight")
         qnn.set_quant_init_done("activation")
