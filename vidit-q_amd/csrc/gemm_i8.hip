@@ -57,6 +57,28 @@ struct GemmArgs {
     int nkt_dbg;  // > 0: run only this many k-tiles (ablation for profiling; results are then wrong)
 };
 
+// Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (bid % 8), each with its own 4 MiB
+// L2, so XCD x takes a CONTIGUOUS range of the tile order below and the 32 tiles it runs at a time share
+// operands through that L2.  Order: super-rows of 8 token tiles; inside a super-row, groups of 4 channel
+// tiles, token tile fastest.  One round of an XCD is then 8 token panels (8 x 256 x K bytes, re-used by
+// every later group of the super-row) x 4 weight panels, 3.7 MB at K = 1152 - instead of 2 token panels x
+// ALL weight panels (5.9 MB at N = 4608, measured 8x over-fetch of the fc1 operands from the fabric:
+// profiles/r01_hbm_traffic.md).  Bijective for any tile counts.
+__device__ __forceinline__ void xcd_tile(int bid, int MT, int NTl, int& mt, int& nt) {
+    constexpr int SM = 8, SN = 4;
+    const int T = MT * NTl;
+    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int per_sr = SM * NTl;
+    const int sr = t / per_sr, rem = t - sr * per_sr;
+    const int smr = MT - sr * SM < SM ? MT - sr * SM : SM;     // token tiles in this super-row
+    const int per_g = smr * SN;
+    const int ng = rem / per_g, r2 = rem - ng * per_g;
+    mt = sr * SM + r2 % smr;
+    nt = ng * SN + r2 / smr;
+}
+
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool W4>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_kernel(GemmArgs a) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -71,12 +93,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_kernel(GemmArgs
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     // ---- XCD-aware tile mapping (bijective for any tile count) ----
-    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    const int T = MT * NTl;
-    const int bid = blockIdx.x;
-    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+    int mt_, nt_;
+    xcd_tile(blockIdx.x, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, mt_, nt_);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -274,12 +293,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_glds_kernel(Gem
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    const int T = MT * NTl;
-    const int bid = blockIdx.x;
-    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+    int mt_, nt_;
+    xcd_tile(blockIdx.x, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, mt_, nt_);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -494,11 +510,86 @@ static int launch_gemm_glds(const GemmArgs& a, hipStream_t st) {
 //     earlier) has landed and every wave has issued its last read of stage kt-1, so the same point
 //     re-issues DMA(kt+2) into that stage; the vmcnt(0) of the barrier only ever waits for a transfer
 //     that had a whole tile of MFMAs to complete.
-// Shared epilogue of the LDS-DMA ring kernels (called after a workgroup barrier; uses all of smem).
+// Per-channel dequant parameters of a tile (sw, -zw, cs, bias): loaded into registers BEFORE the first DMA
+// batch is issued and parked in the LDS block behind the epilogue slabs AFTER it (PAR_OFF lies past the end
+// of every ring), so neither the load latency nor the staging sits on the critical path.
+struct ColParams {
+    float sw, b;
+    int nzw, cs;
+};
+template <int BN>
+__device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int n0) {
+    ColParams c{0.f, 0.f, 0, 0};
+    const int gn = n0 + (int)threadIdx.x;
+    if ((int)threadIdx.x < BN && gn < a.N) {
+        c.sw = a.sw[gn];
+        c.nzw = -a.zw[gn];
+        c.cs = a.cs[gn];
+        c.b = a.bias ? a.bias[gn] : 0.f;
+    }
+    return c;
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void ring_park_col_params(const ColParams& c, uint8_t* smem) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
+    static_assert(BN <= NT, "one channel per thread");
+    constexpr int PAR_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16);
+    if ((int)threadIdx.x < BN) {
+        reinterpret_cast<float*>(smem + PAR_OFF)[threadIdx.x] = c.sw;
+        reinterpret_cast<int*>(smem + PAR_OFF)[BN + threadIdx.x] = c.nzw;
+        reinterpret_cast<int*>(smem + PAR_OFF)[2 * BN + threadIdx.x] = c.cs;
+        reinterpret_cast<float*>(smem + PAR_OFF)[3 * BN + threadIdx.x] = c.b;
+    }
+}
+
+// Per-token dequant parameters (sx, -zx, R) of the tile's BM token rows travel the same way: one row per
+// thread, loaded before the first DMA batch, parked behind the channel block (BM * 12 bytes).
+struct RowParams {
+    float sx;
+    int nzx, R;
+};
+template <int BM>
+__device__ __forceinline__ RowParams ring_load_row_params(const GemmArgs& a, int m0) {
+    RowParams r{0.f, 0, 0};
+    if ((int)threadIdx.x < BM) {
+        const int m = m0 + (int)threadIdx.x;
+        const int mc = m < a.M ? m : a.M - 1;
+        r.sx = a.sx[mc];
+        r.nzx = -a.zx[mc];
+        r.R = a.R[mc];
+    }
+    return r;
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t* smem) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
+    static_assert(BM <= NT, "one token row per thread");
+    constexpr int ROW_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 16 * BN;
+    static_assert(ROW_OFF + 12 * BM <= 163840, "LDS budget");
+    if ((int)threadIdx.x < BM) {
+        reinterpret_cast<float*>(smem + ROW_OFF)[threadIdx.x] = r.sx;
+        reinterpret_cast<int*>(smem + ROW_OFF)[BM + threadIdx.x] = r.nzx;
+        reinterpret_cast<int*>(smem + ROW_OFF)[2 * BM + threadIdx.x] = r.R;
+    }
+}
+
+// Stage both parameter blocks (called once all fragment reads of the main loop are issued; the blocks lie
+// past the end of every ring, so no barrier is needed before writing them, only before reading them).
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* smem, int m0, int n0) {
+    const ColParams colp = ring_load_col_params<BN>(a, n0);
+    const RowParams rowp = ring_load_row_params<BM>(a, m0);
+    ring_park_col_params<BM, BN, WAVES_M, WAVES_N>(colp, smem);
+    ring_park_row_params<BM, BN, WAVES_M, WAVES_N>(rowp, smem);
+}
+
+// Shared epilogue of the LDS-DMA ring kernels (called after a workgroup barrier; uses all of smem; the
+// parameter block must have been staged by ring_stage_params and made visible by that barrier).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
-                                              int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0) {
-    constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
+                                              int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
+                                              long long* ts = nullptr) {
+    constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -514,36 +605,30 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
     constexpr int ROWB = WTN * 2 + 16;                // slab row stride in bytes (16 B aligned; 2-way write conflicts)
     constexpr int SLAB = WTM * ROWB;
     constexpr int PAR_OFF = NW * SLAB;                // per-channel parameter block behind the slabs
-    float* l_sw = reinterpret_cast<float*>(smem + PAR_OFF);
-    int* l_zw = reinterpret_cast<int*>(smem + PAR_OFF) + BN;
-    int* l_cs = reinterpret_cast<int*>(smem + PAR_OFF) + 2 * BN;
-    float* l_b = reinterpret_cast<float*>(smem + PAR_OFF) + 3 * BN;
-    for (int c = tid; c < BN; c += NT) {
-        const int gn = n0 + c;
-        const bool ok = gn < a.N;
-        l_sw[c] = ok ? a.sw[gn] : 0.f;
-        l_zw[c] = ok ? a.zw[gn] : 0;
-        l_cs[c] = ok ? a.cs[gn] : 0;
-        l_b[c] = (ok && a.bias) ? a.bias[gn] : 0.f;
-    }
-    __syncthreads();
+    const float* l_sw = reinterpret_cast<const float*>(smem + PAR_OFF);
+    const int* l_nzw = reinterpret_cast<const int*>(smem + PAR_OFF) + BN;
+    const int* l_cs = reinterpret_cast<const int*>(smem + PAR_OFF) + 2 * BN;
+    const float* l_b = reinterpret_cast<const float*>(smem + PAR_OFF) + 3 * BN;
+    const float* l_sx = reinterpret_cast<const float*>(smem + PAR_OFF + 16 * BN);
+    const int* l_nzx = reinterpret_cast<const int*>(smem + PAR_OFF + 16 * BN) + BM;
+    const int* l_R = reinterpret_cast<const int*>(smem + PAR_OFF + 16 * BN) + 2 * BM;
     uint8_t* slab = smem + wave * SLAB;
+    if (ts) ts[3] = __builtin_readcyclecounter();
     {
         float sxm[TM];
-        int zxm[TM], Rm[TM];
+        int nzx[TM], Rm[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + frow;
-            const int mc = m < a.M ? m : a.M - 1;
-            sxm[i] = a.sx[mc];
-            zxm[i] = a.zx[mc];
-            Rm[i] = a.R[mc];
+            const int rl = wm * WTM + i * 16 + frow;
+            sxm[i] = l_sx[rl];
+            nzx[i] = l_nzx[rl];
+            Rm[i] = l_R[rl];
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = wn * WTN + j * 16 + 4 * fc;
             const float4v fsw_ = *reinterpret_cast<const float4v*>(l_sw + nl);
-            const int4v izw = *reinterpret_cast<const int4v*>(l_zw + nl);
+            const int4v nzw = *reinterpret_cast<const int4v*>(l_nzw + nl);
             const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
             const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
 #pragma unroll
@@ -551,7 +636,8 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int tt = acc[j][i][e] - __mul24(izw[e], Rm[i]) - __mul24(zxm[i], ics[e]);
+                    // acc - zw*R - zx*cs, exact in int32: two v_mad_i32_i24 (|zw|,|zx| < 2^8, |R|,|cs| < 2^23)
+                    const int tt = __mul24(nzx[i], ics[e]) + (__mul24(nzw[e], Rm[i]) + acc[j][i][e]);
                     float y = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
                     if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
                     o[e] = (half_t)y;
@@ -560,6 +646,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
             }
         }
     }
+    if (ts) ts[4] = __builtin_readcyclecounter();
     // second pass: this wave's slab, row-major 16-byte chunks (same wave wrote it: LDS ops are in order)
     constexpr int CPR = WTN / 8;                      // 16-byte chunks per slab row
     constexpr int NCH = WTM * CPR;
@@ -599,6 +686,12 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
             *reinterpret_cast<half4*>(a.out + off) = y4;
         }
     }
+    if (ts) {
+        ts[5] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[6] = __builtin_readcyclecounter();
+        ts[8] = wall_clock64();
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool STAGGER, bool W4>
@@ -630,12 +723,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    const int T = MT * NTl;
-    const int bid = blockIdx.x;
-    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+    int mt_, nt_;
+    xcd_tile(blockIdx.x, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, mt_, nt_);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -778,6 +868,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pipe_kernel(Gem
         }
     }
 #undef VQ_PIPE_TILE
+    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0);
     __syncthreads();
 
     ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0);
@@ -787,7 +878,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE, bool ST
 static int launch_gemm_pipe_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t RING = NSTAGE * ((size_t)BM * 64 + (size_t)BN * (W4 ? 32 : 64));
-    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4;
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4 + 12 * BM;
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
@@ -844,13 +935,18 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // ABL & 16: cycle-counter stamps of every wave -> a.gate reinterpreted as long long[tiles][waves][10] (0-6 shader cycles, 7/8 100 MHz wall clock at start/end)
+    long long* ts = nullptr;
+    if constexpr ((ABL & 16) != 0)
+        ts = reinterpret_cast<long long*>(const_cast<float*>(a.gate)) + ((size_t)blockIdx.x * (WAVES_M * WAVES_N) + (threadIdx.x >> 6)) * 10;
+    if (ts) {
+        ts[7] = wall_clock64();
+        ts[0] = __builtin_readcyclecounter();
+    }
 
-    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    const int T = MT * NTl;
-    const int bid = blockIdx.x;
-    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+    int mt_, nt_;
+    xcd_tile(blockIdx.x, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, mt_, nt_);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -935,6 +1031,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if (ts) ts[1] = __builtin_readcyclecounter();
     int4v xa[TM], xb[TM];
     WRaw w[3];
 #pragma unroll
@@ -984,15 +1081,17 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
         VQ_WIDE_STEP(xb, xa, 1)
     }
 #undef VQ_WIDE_STEP
+    if (ts) ts[2] = __builtin_readcyclecounter();
+    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0);
     __syncthreads();
-    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0);
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
 static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
-    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4;
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4 + 12 * BM;
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
@@ -1046,12 +1145,9 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pp_kernel(GemmA
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    const int T = MT * NTl;
-    const int bid = blockIdx.x;
-    const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int m0 = (t / NTl) * BM, n0 = (t % NTl) * BN;
+    int mt_, nt_;
+    xcd_tile(blockIdx.x, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, mt_, nt_);
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1184,6 +1280,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pp_kernel(GemmA
             __builtin_amdgcn_s_barrier();
         }
     }
+    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0);
     __syncthreads();
     ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0);
 }
@@ -1192,7 +1289,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4>
 static int launch_gemm_pp_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
-    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4;
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4 + 12 * BM;
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
@@ -1307,18 +1404,18 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         default:
             break;
     }
-    if (variant >= 100 && variant < 116 && w_bits > 4) {   // profiling ablations of variant 11 (wrong results)
+    if (variant >= 100 && variant < 132 && w_bits > 4) {   // profiling ablations of variant 11 (wrong results)
 #define VQ_ABL(A)                                                                                               \
     case 100 + A: {                                                                                             \
         auto k = gemm_i8_wide_kernel<256, 288, 4, 2, VQ_EPI_NONE, true, false, A>;                              \
         static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160256);          \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 163328);          \
         (void)e;                                                                                                \
-        hipLaunchKernelGGL(k, dim3(((M + 255) / 256) * ((N + 287) / 288)), dim3(512), 160256, st, a);           \
+        hipLaunchKernelGGL(k, dim3(((M + 255) / 256) * ((N + 287) / 288)), dim3(512), 163328, st, a);           \
         return vq_check_launch();                                                                               \
     }
         switch (variant) {
-            VQ_ABL(1) VQ_ABL(2) VQ_ABL(3) VQ_ABL(4) VQ_ABL(5) VQ_ABL(8) VQ_ABL(9) VQ_ABL(10) VQ_ABL(12) VQ_ABL(13)
+            VQ_ABL(1) VQ_ABL(2) VQ_ABL(3) VQ_ABL(4) VQ_ABL(5) VQ_ABL(8) VQ_ABL(9) VQ_ABL(10) VQ_ABL(12) VQ_ABL(13) VQ_ABL(16)
             default: break;
         }
 #undef VQ_ABL
