@@ -12,6 +12,7 @@ from viditq_amd import ops
 dev = torch.device("cuda:0")
 M = 16384
 g = torch.Generator().manual_seed(0)
+VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 116     # 116 = full-line ring (11), 117 = ping-pong (13)
 for (N, K) in [(1152, 1152), (4608, 1152), (1152, 4608)]:
     x = torch.randn(1, M, K, generator=g).half().to(dev)
     W = (torch.randn(N, K, generator=g) * 0.03).half().to(dev)
@@ -22,7 +23,7 @@ for (N, K) in [(1152, 1152), (4608, 1152), (1152, 4608)]:
     tiles = (M // 256) * (N // 288)
     stamps = torch.zeros(tiles * 8 * 10, dtype=torch.int64, device=dev)
     for _ in range(3):
-        ops.gemm_i8(qa, pw, out=out, variant=116, gate=stamps.view(torch.float32))
+        ops.gemm_i8(qa, pw, out=out, variant=VARIANT, gate=stamps.view(torch.float32))
     torch.cuda.synchronize()
     s = stamps.view(tiles, 8, 10).cpu().double()
     t0 = s[:, :, 0].min()                       # first wave start on the chip

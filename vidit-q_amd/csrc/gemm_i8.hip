@@ -33,11 +33,13 @@ __device__ __forceinline__ int swz(int row) {
 }
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // nn.GELU(approximate='tanh'): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float e = __expf(2.0f * u);
-    const float th = 1.0f - __fdiv_rn(2.0f, e + 1.0f);
-    return 0.5f * x * (1.0f + th);
+    // nn.GELU(approximate='tanh'): 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715 x^3)
+    //   = x * sigmoid(2u) = x / (1 + 2^(-2u*log2 e)):  3 fma/mul + v_exp_f32 + v_rcp_f32 (1 ulp each; the result
+    // is rounded to fp16 right after) instead of an IEEE division and an exp with range reduction.
+    const float x2 = x * x;
+    const float w = x * fmaf(x2, -0.044715f * 2.302208198f, -2.302208198f);   // -2u*log2(e); 2*sqrt(2/pi)*log2(e) = 2.3022082
+    const float e = __builtin_amdgcn_exp2f(w);                                 // +inf for very negative x -> y = -0
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 struct GemmArgs {
@@ -636,8 +638,11 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    // acc - zw*R - zx*cs, exact in int32: two v_mad_i32_i24 (|zw|,|zx| < 2^8, |R|,|cs| < 2^23)
-                    const int tt = __mul24(nzx[i], ics[e]) + (__mul24(nzw[e], Rm[i]) + acc[j][i][e]);
+                    // acc - zw*R - zx*cs, exact in int32: two v_mad_i32_i24 (|zw|,|zx| < 2^8, |R|,|cs| < 2^23);
+                    // written as asm because the compiler otherwise emits 2 x v_mul_i32_i24 + v_add3_u32
+                    int t1, tt;
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(nzw[e]), "v"(Rm[i]), "v"(acc[j][i][e]));
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(tt) : "v"(nzx[i]), "v"(ics[e]), "v"(t1));
                     float y = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
                     if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
                     o[e] = (half_t)y;
@@ -1130,7 +1135,9 @@ static int launch_gemm_wide(const GemmArgs& a, hipStream_t st) {
 //   stage T is read in segments 4T-1 .. 4T+2, refilled with tile T+2 in segments 4T+3 (A's pieces) and
 //   4T+4 (B's pieces), and every wave drains its DMA (vmcnt(0)) before the barrier that ends segment 4T+6.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4>
+// SEGBAR: barrier after EVERY segment (variant 13) or only the one per 128-byte stage that hands LDS stages
+// over (variant 15: the partners start each stage in opposite roles and drift freely inside it).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4, bool STAMPS = false, bool SEGBAR = true, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pp_kernel(GemmArgs a) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -1144,6 +1151,13 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pp_kernel(GemmA
     static_assert(WTM % 16 == 0 && WTN % 16 == 0 && NW % 2 == 0, "tiling");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    long long* ts = nullptr;
+    if constexpr (STAMPS)
+        ts = reinterpret_cast<long long*>(const_cast<float*>(a.gate)) + ((size_t)blockIdx.x * (WAVES_M * WAVES_N) + (threadIdx.x >> 6)) * 10;
+    if (ts) {
+        ts[7] = wall_clock64();
+        ts[0] = __builtin_readcyclecounter();
+    }
 
     int mt_, nt_;
     xcd_tile(blockIdx.x, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, mt_, nt_);
@@ -1246,6 +1260,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pp_kernel(GemmA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if (ts) ts[1] = __builtin_readcyclecounter();
     if (!late) {
         load_frags(0);
         for (int s = 0; s < S; ++s) {
@@ -1254,38 +1269,41 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_pp_kernel(GemmA
             compute();
             __builtin_amdgcn_sched_barrier(0);
             if (s & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (SEGBAR || (s & 1)) __builtin_amdgcn_s_barrier();
             // ---- segment 2s + 1: load
             __builtin_amdgcn_sched_barrier(0);
-            if ((s & 1) && ((s + 3) >> 1) < nkt) issue(((s + 3) >> 1) & 1, (s + 3) >> 1);
-            if (s + 1 < S) load_frags(s + 1);
+            if (!(ABL & 1) && (s & 1) && ((s + 3) >> 1) < nkt) issue(((s + 3) >> 1) & 1, (s + 3) >> 1);
+            if (!(ABL & 8) && s + 1 < S) load_frags(s + 1);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the stage can be refilled
-            __builtin_amdgcn_s_barrier();
+            if (SEGBAR) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the stage can be refilled
+                __builtin_amdgcn_s_barrier();
+            }
         }
     } else {
         for (int s = 0; s < S; ++s) {
             // ---- segment 2s: load
             __builtin_amdgcn_sched_barrier(0);
-            if (!(s & 1) && s >= 2 && (s >> 1) + 1 < nkt) issue(((s >> 1) + 1) & 1, (s >> 1) + 1);
-            load_frags(s);
+            if (!(ABL & 1) && !(s & 1) && s >= 2 && (s >> 1) + 1 < nkt) issue(((s >> 1) + 1) & 1, (s >> 1) + 1);
+            if (!(ABL & 8) || s == 0) load_frags(s);
             __builtin_amdgcn_sched_barrier(0);
             if (s & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            else if (SEGBAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (SEGBAR || (s & 1)) __builtin_amdgcn_s_barrier();
             // ---- segment 2s + 1: compute
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+            if (SEGBAR) __builtin_amdgcn_s_barrier();
         }
     }
+    if (ts) ts[2] = __builtin_readcyclecounter();
     ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0);
     __syncthreads();
-    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0);
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4, bool SEGBAR>
 static int launch_gemm_pp_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
@@ -1293,7 +1311,7 @@ static int launch_gemm_pp_e(const GemmArgs& a, hipStream_t st) {
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    auto k = gemm_i8_pp_kernel<BM, BN, WAVES_M, WAVES_N, EPI, W4>;
+    auto k = gemm_i8_pp_kernel<BM, BN, WAVES_M, WAVES_N, EPI, W4, false, SEGBAR>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
     if (e != hipSuccess) {
@@ -1304,13 +1322,13 @@ static int launch_gemm_pp_e(const GemmArgs& a, hipStream_t st) {
     return vq_check_launch();
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool W4 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool W4 = false, bool SEGBAR = true>
 static int launch_gemm_pp(const GemmArgs& a, hipStream_t st) {
     switch (a.epilogue) {
-        case VQ_EPI_NONE: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, W4>(a, st);
-        case VQ_EPI_GELU: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, W4>(a, st);
-        case VQ_EPI_GATE_RESID: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, W4>(a, st);
-        default: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, W4>(a, st);
+        case VQ_EPI_NONE: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, W4, SEGBAR>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, W4, SEGBAR>(a, st);
+        case VQ_EPI_GATE_RESID: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, W4, SEGBAR>(a, st);
+        default: return launch_gemm_pp_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, W4, SEGBAR>(a, st);
     }
 }
 
@@ -1398,6 +1416,9 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         case 13:  // ping-pong: SIMD partners alternate MFMA-only and load-only segments
             if (w_bits <= 4) return launch_gemm_pp<256, 288, 4, 2, true>(a, st);
             return launch_gemm_pp<256, 288, 4, 2>(a, st);
+        case 15:  // ping-pong with ONE barrier per 128-byte stage (roles re-seeded at every stage hand-over)
+            if (w_bits <= 4) return launch_gemm_pp<256, 288, 4, 2, true, false>(a, st);
+            return launch_gemm_pp<256, 288, 4, 2, false, false>(a, st);
         case 12:  // same without the stagger (comparison)
             if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, false, true>(a, st);
             return launch_gemm_wide<256, 288, 4, 2, false>(a, st);
@@ -1414,6 +1435,18 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         hipLaunchKernelGGL(k, dim3(((M + 255) / 256) * ((N + 287) / 288)), dim3(512), 163328, st, a);           \
         return vq_check_launch();                                                                               \
     }
+        if (variant >= 117 && variant <= 121) {
+            auto k = variant == 117   ? gemm_i8_pp_kernel<256, 288, 4, 2, VQ_EPI_NONE, false, true, true>
+                     : variant == 118 ? gemm_i8_pp_kernel<256, 288, 4, 2, VQ_EPI_NONE, false, true, false>
+                     : variant == 119 ? gemm_i8_pp_kernel<256, 288, 4, 2, VQ_EPI_NONE, false, true, false, 1>
+                     : variant == 120 ? gemm_i8_pp_kernel<256, 288, 4, 2, VQ_EPI_NONE, false, true, false, 8>
+                                      : gemm_i8_pp_kernel<256, 288, 4, 2, VQ_EPI_NONE, false, true, false, 9>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 163328);
+            (void)e;
+            hipLaunchKernelGGL(k, dim3(((M + 255) / 256) * ((N + 287) / 288)), dim3(512), 163328, st, a);
+            return vq_check_launch();
+        }
         switch (variant) {
             VQ_ABL(1) VQ_ABL(2) VQ_ABL(3) VQ_ABL(4) VQ_ABL(5) VQ_ABL(8) VQ_ABL(9) VQ_ABL(10) VQ_ABL(12) VQ_ABL(13) VQ_ABL(16)
             default: break;
