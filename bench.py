@@ -188,9 +188,17 @@ def main():
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)
         tot_ops = sum(o for _, _, o, _ in timing)
         ach = tot_ops / (tot_ms * 1e-3)
+        # HBM / fabric bytes per GEMM launch: PMC passes cannot run inside this process; the committed measurement
+        # of the same command (tools/pmc_traffic.sh -> profiles/r01_gemm_traffic.json) is reported for this plan
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if a.plan == "w8a8" and os.path.exists(tj):
+            with open(tj) as f:
+                t_ = json.load(f)
+            traffic, traffic_src = t_["hbm_bytes_per_launch"], t_["source"]
         roof = {"bound": "mfma", "kernel": "gemm_i8_wide_kernel<256,288,4,2,EPI,stagger> (W8A8 Linear: int8 MFMA 16x16x64, full-line LDS-DMA double buffer, fused dequant epilogue)",
                 "achieved": ach / 1e12, "peak": PEAK_INT8 / 1e12, "unit": "TFLOP/s", "frac": ach / PEAK_INT8,
-                "traffic": None, "launches": len(timing), "avg_launch_us": tot_ms * 1e3 / len(timing),
+                "traffic": traffic, "traffic_source": traffic_src, "launches": len(timing), "avg_launch_us": tot_ms * 1e3 / len(timing),
                 "gemm_time_share_of_step": tot_ms * 1e-3 / el,
                 "measured": "HIP events around every GEMM launch, eager re-run of the same K steps after the timed region",
                 "algorithmic_bytes_per_launch_avg": sum(b for _, _, _, b in timing) / len(timing)}
