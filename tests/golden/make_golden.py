@@ -387,6 +387,21 @@ def tiny_pixart():
             for bn, bv in bufs.items():
                 if bv is not None:
                     out["qp/%s/%s" % (name, bn)] = bv
+        # the t2i sampling loop of quant_txt2img.py:130-153 driven by the reference's own DPM-Solver: 5 steps,
+        # cfg 4.5, one batched (uncond | cond) forward per step on the quantized model
+        import importlib
+        dps = importlib.import_module("diffusion.dpm_solver_sigma")
+        z = h(torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(77)))
+        null_y = h(torch.randn(1, 1, 12, 32, generator=torch.Generator().manual_seed(78)) * 0.5)
+        solver = dps.DPMS_sigma(m.forward_with_dpmsolver, condition=y[:1], uncondition=null_y, cfg_scale=4.5,
+                                model_kwargs=dict(data_info=None, mask=mask[:1]))
+        out["dpm_z"], out["dpm_null_y"] = z, null_y
+        out["dpm_final"] = solver.sample(z, steps=5, order=2, skip_type="time_uniform", method="multistep")
+        ns = solver.noise_schedule
+        tt = torch.linspace(1.0, 0.001, 6)
+        out["dpm_lambda"] = ns.marginal_lambda(tt)
+        out["dpm_log_alpha"] = ns.marginal_log_mean_coeff(tt)
+        out["dpm_total_N"] = np.array(ns.total_N)
     npz("tiny_pixart_w8a8.npz", **out)
 
 

@@ -376,3 +376,35 @@ def test_tiny_pixart_w8a8_fused_path(dev, ops):
     assert rel_l2(out1.cpu().float(), g["w8a8_b1"]) < 5e-3
     qnn.set_quant_state(False, False)
     assert rel_l2(qnn(x, t, y, mask=mask).cpu().float(), g["fp"]) < 3e-3
+
+
+def test_tiny_pixart_dpm_solver_trajectory(dev, ops):
+    """The t2i sampling loop (quant_txt2img.py:130-153): DPM-Solver++ 2M, cfg 4.5, one batched (uncond | cond)
+    forward of the quantized PixArt-MS per step, vs the trajectory the reference's solver produced."""
+    import viditq_amd  # noqa
+    from viditq_amd.qdiff.models import QuantModel
+    from viditq_amd.qdiff.quantizer import BaseQuantizer
+    from viditq_amd.t2i import PixArtMS
+    from viditq_amd.t2i.dpm_solver import DPMS_sigma
+    g = load_npz("tiny_pixart_w8a8.npz")
+    m = PixArtMS(input_size=16, depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32,
+                 dtype=torch.float16)
+    m.load_state_dict(state_dict_of(g), strict=True)
+    m = m.half().to(dev).eval()
+    wq, aq = _cfgs(8)
+    aq["n_spatial_token"], aq["n_temporal_token"] = 64, 1
+    qnn = QuantModel(m, wq, aq, model_type="pixart")
+    qnn.set_module_name_for_quantizer(qnn.model)
+    qnn.fp_layer_list = ["x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder"]
+    qp = quant_params_of(g)
+    qnn.set_quant_params_dict({mod.module_name: [qp.get(mod.module_name, {}), {}] for mod in qnn.model.modules()
+                               if isinstance(mod, BaseQuantizer)})
+    qnn.set_quant_init_done("weight")
+    qnn.set_quant_init_done("activation")
+    qnn.set_quant_state(True, True)
+    solver = DPMS_sigma(qnn.forward_with_dpmsolver, condition=g["y"][:1].half().to(dev),
+                        uncondition=g["dpm_null_y"].half().to(dev), cfg_scale=4.5,
+                        model_kwargs=dict(data_info=None, mask=g["mask"][:1].to(dev)))
+    out = solver.sample(g["dpm_z"].to(dev), steps=5, order=2, skip_type="time_uniform", method="multistep")
+    # 5 guided steps (cfg 4.5 amplifies the cond/uncond difference) on fp16 activations and fp16 timesteps
+    assert rel_l2(out.cpu().float(), g["dpm_final"]) < 2e-2

@@ -169,3 +169,39 @@ def test_tiny_pixart_w8a8():
     out1 = pr.pixart_forward(sd, cfg, x[:1], t[:1], y[:1], mask[:1], spec, g["pos_embed"])
     assert rel_l2(out1, g["w8a8_b1"]) < 1e-5
     assert rel_l2(out[:1], out1) > 1e-4                         # batch-shared token scales change the result
+
+
+def _import_dpm():
+    """The solver is host logic of the product (pure torch, device-agnostic): load it by path so that this CPU
+    test does not need the HIP library."""
+    import importlib.util
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vidit-q_amd", "t2i", "dpm_solver.py")
+    spec = importlib.util.spec_from_file_location("vq_dpm_solver", p)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_dpm_solver_schedule_and_trajectory_vs_reference():
+    """DPM-Solver++ 2M restatement: schedule scalars equal to the reference's NoiseScheduleVP, and a 5-step
+    guided trajectory of the quantized tiny PixArt (oracle forward as the model) equal to the reference's."""
+    from oracle import pixart_ref as pr
+    dpm = _import_dpm()
+    g = load_npz("tiny_pixart_w8a8.npz")
+    ns = dpm.NoiseScheduleVP(dpm.linear_betas(1000))
+    assert ns.total_N == int(g["dpm_total_N"])
+    tt = torch.linspace(1.0, 0.001, 6)
+    assert torch.allclose(ns.marginal_log_mean_coeff(tt), g["dpm_log_alpha"], rtol=0, atol=1e-7)
+    assert torch.allclose(ns.marginal_lambda(tt), g["dpm_lambda"], rtol=1e-6, atol=1e-6)
+    sd = state_dict_of(g)
+    cfg = dict(H=4, depth=2, patch=2, out_ch=8)
+    spec = sr.QSpec(w_bits=8, fp_layers=pr.T2I_FP_LAYERS)
+
+    def model(x, t, y, data_info=None, mask=None):           # forward_with_dpmsolver: first half of the channels
+        m_ = mask if mask.shape[0] == y.shape[0] else mask.repeat(y.shape[0] // mask.shape[0], 1)
+        return pr.pixart_forward(sd, cfg, x, t, y, m_, spec, g["pos_embed"]).chunk(2, dim=1)[0]
+    solver = dpm.DPMS_sigma(model, condition=g["y"][:1], uncondition=g["dpm_null_y"], cfg_scale=4.5,
+                            model_kwargs=dict(data_info=None, mask=g["mask"][:1]))
+    out = solver.sample(g["dpm_z"], steps=5, order=2, skip_type="time_uniform", method="multistep")
+    assert rel_l2(out, g["dpm_final"]) < 1e-4
