@@ -19,6 +19,7 @@
 // workgroup = 2 spatial positions x 4 heads, rows staged once through LDS with full-width
 // coalesced loads, one wave per head, 32x32 MFMA over the 2x16 token rows with a
 // block-diagonal mask.
+#include <stdlib.h>
 #include "vq_common.h"
 
 #define ATT_LOG2E 1.4426950408889634f
@@ -379,10 +380,330 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(TempArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// attn_fwd8_kernel: second generation of the flash kernel above for long query sequences.
+//   * 8 waves (256 queries) share one K/V tile: half the staging work and LDS traffic per query;
+//   * V is staged DIM-major: Vt[d][32 key pairs] dwords, pair order permuted so that the four dwords an
+//     MFMA A-operand lane needs (keys {4g..4g+3} and {8+4g..8+4g+3} of a 16-key step: the order in which
+//     S^T leaves the first MFMA) are one 16-byte slot -> ONE ds_read_b128 with an immediate-free per-lane
+//     address per MFMA (the pair-major image needed 4 ds_read_b32 + address arithmetic: 48 reads and 75
+//     v_add_u32 per key tile).  Row stride 144 B (9 slots: conflict-free b128 reads across dims); the slot
+//     index is rotated by d >> 4 so that the 4-byte staging writes of different 8-dim chunks spread over
+//     the banks; row D is all {1.0, 1.0}: the P.V MFMA of that row yields the softmax row sums;
+//   * the partner exchange of the key pair (lanes c, c^1) is a DPP quad_perm, not ds_bpermute;
+//   * deferred rescale: the running max (and O) is updated only when some lane's tile max exceeds it by
+//     more than 8 in the exp2 domain, so P <= 2^8 in between (fp16-safe) and the 48-register rescale of
+//     O^T runs on the first tiles only.
+// ---------------------------------------------------------------------------
+template <int D, int NW>
+struct Att8Cfg {
+    static constexpr int KS = (D + 15) / 16;
+    static constexpr int DT = (D + 32) / 32;
+    static constexpr int CHD = D / 8;
+    static constexpr int KROW = (CHD | 1) * 16;
+    static constexpr int VROWB = 144;
+    static constexpr int KTILE = 64 * KROW;
+    static constexpr int VTILE = (D + 1) * VROWB;
+    static constexpr int LDS = 2 * (KTILE + VTILE);
+    static constexpr int KCH = 64 * CHD;
+    static constexpr int NTH = 64 * NW;
+    static constexpr int KPT = (KCH + NTH - 1) / NTH;
+    static_assert(DT * 32 > D, "needs a spare O^T row for the row sums");
+};
+
+// ABL (profiling only, wrong results): 1 no exp, 2 no P.V MFMAs, 4 no QK MFMAs, 8 no staging after tile 0
+template <int D, int NW, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_fwd8_kernel(AttnArgs a) {
+    using C = Att8Cfg<D, NW>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    // Workgroup -> (sequence, head, query tile).  Workgroups are dealt round-robin to the 8 XCDs; XCD x takes a
+    // CONTIGUOUS range of the (sequence, head) pairs and runs the query tiles of a pair back to back, so a
+    // pair's K/V panel is fetched into that XCD's L2 once for all its query tiles, and neighbouring heads
+    // (whose 2*D-byte row segments share cache lines) sit in the same L2.  With the plain (qt, h, seq) grid
+    // the 4 query tiles of a pair ran on 4 different XCDs: 341 MB read for 113 MB of q/k/v
+    // (profiles/r01_hbm_traffic.md), and re-staging K/V cost 50 of 188 us.
+    int qt, h, seq;
+    {
+        const int nqt = (a.Lq + 32 * NW - 1) / (32 * NW);
+        const int G = a.n_seq * a.H;
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+        const int q8 = G / 8, r8 = G % 8;
+        const int gbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        const int gcount = xcd < r8 ? q8 + 1 : q8;
+        const int pl = idx / nqt;
+        if (pl >= gcount) return;                      // padded grid slot (whole workgroup: no barrier reached yet)
+        const int pair = gbase + pl;
+        qt = idx - pl * nqt;
+        seq = pair / a.H;
+        h = pair - seq * a.H;
+    }
+
+    int kv_len = a.Lk;
+    const half_t* kbase;
+    const half_t* vbase;
+    if (a.kv_off) {
+        const int o0 = a.kv_off[seq];
+        kv_len = a.kv_off[seq + 1] - o0;
+        kbase = a.k + (long)o0 * a.kv_tok_stride + h * D;
+        vbase = a.v + (long)o0 * a.kv_tok_stride + h * D;
+    } else {
+        kbase = a.k + (long)seq * a.kv_seq_stride + h * D;
+        vbase = a.v + (long)seq * a.kv_seq_stride + h * D;
+    }
+    const int qi = qt * (32 * NW) + wave * 32 + l31;
+    const bool q_ok = qi < a.Lq;
+    const int qc = q_ok ? qi : a.Lq - 1;
+    const half_t* qrow = a.q + (long)seq * a.q_seq_stride + (long)qc * a.q_tok_stride + h * D;
+
+    half8 qf[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        const int d0 = ks * 16 + 8 * g;
+        if (d0 < D) qf[ks] = *reinterpret_cast<const half8*>(qrow + d0);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)0.f;
+    }
+
+    float16v oacc[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY;
+
+    // V^T fragment addresses: lane = output dim d (row D = the ones row; rows above it are clamped, unused)
+    int vaddr[C::DT][4];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+        const int d = dt * 32 + l31 <= D ? dt * 32 + l31 : D;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) vaddr[dt][kk] = d * C::VROWB + (((2 * kk + g + (d >> 4)) & 7) << 4);
+    }
+
+    const int nkt = (kv_len + 63) / 64;
+    // two staging register sets: tile t travels in set t & 1 and is loaded TWO tiles ahead
+    int4v krA[C::KPT], vrA[C::KPT], krB[C::KPT], vrB[C::KPT];
+    // Per-thread staging geometry, computed ONCE (the divisions by CHD and the swizzles cost ~100 VALU per tile
+    // when redone in the loop).  Chunk c of a tile: K row c / CHD, 16-byte piece c % CHD; V: lanes c, c^1 hold
+    // the same 8-dim piece of keys 2p, 2p+1 (p = (c >> 1) / CHD).  The ragged last pass (KCH % NTH chunks) is
+    // taken by a FIXED set of waves here (rotating it would make the geometry tile-dependent).
+    bool act[C::KPT];
+    int krow[C::KPT], vrow[C::KPT];                   // key row inside the tile (K: row; V: 2p + odd)
+    long kgo[C::KPT], vgo[C::KPT];                    // global element offsets of the chunk inside a tile
+    int kdst[C::KPT], vdst[C::KPT];                   // LDS byte offsets inside a buffer
+#pragma unroll
+    for (int i = 0; i < C::KPT; ++i) {
+        const int c = tid + i * C::NTH;
+        act[i] = c < C::KCH;
+        const int cc = act[i] ? c : 0;
+        krow[i] = cc / C::CHD;
+        kgo[i] = (long)krow[i] * a.kv_tok_stride + (cc % C::CHD) * 8;
+        kdst[i] = krow[i] * C::KROW + (cc % C::CHD) * 16;
+        const int odd = cc & 1, m = cc >> 1, p = m / C::CHD, dch = m % C::CHD;
+        vrow[i] = 2 * p + odd;
+        vgo[i] = (long)vrow[i] * a.kv_tok_stride + dch * 8;
+        const int q = 2 * (p >> 3) + ((p >> 1) & 1), idx = (p & 1) + 2 * ((p >> 2) & 1);
+        vdst[i] = (8 * dch + 4 * odd) * C::VROWB + ((((q + (dch >> 1)) & 7) << 2) + idx) * 4;
+    }
+    const bool odd_lane = tid & 1;                     // c & 1 == tid & 1 for every pass (NTH is even)
+    auto load_tile = [&](int kt, int4v (&kr)[C::KPT], int4v (&vr)[C::KPT]) {
+        const long t0 = (long)kt * 64 * a.kv_tok_stride;
+        const bool full = kt * 64 + 64 <= kv_len;      // wave-uniform: no clamping on full tiles
+#pragma unroll
+        for (int i = 0; i < C::KPT; ++i) {
+            if (act[i]) {
+                if (full) {
+                    kr[i] = *reinterpret_cast<const int4v*>(kbase + t0 + kgo[i]);
+                    vr[i] = *reinterpret_cast<const int4v*>(vbase + t0 + vgo[i]);
+                } else {
+                    const int kk_ = kt * 64 + krow[i] < kv_len ? krow[i] : kv_len - 1 - kt * 64;
+                    const int vk_ = kt * 64 + vrow[i] < kv_len ? vrow[i] : kv_len - 1 - kt * 64;
+                    kr[i] = *reinterpret_cast<const int4v*>(kbase + t0 + kgo[i] + (long)(kk_ - krow[i]) * a.kv_tok_stride);
+                    vr[i] = *reinterpret_cast<const int4v*>(vbase + t0 + vgo[i] + (long)(vk_ - vrow[i]) * a.kv_tok_stride);
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf, int4v (&kr)[C::KPT], int4v (&vr)[C::KPT]) {
+        uint8_t* kt_ = smem + buf * C::KTILE;
+        uint8_t* vt_ = smem + 2 * C::KTILE + buf * C::VTILE;
+#pragma unroll
+        for (int i = 0; i < C::KPT; ++i) {
+            if (act[i]) {
+                *reinterpret_cast<int4v*>(kt_ + kdst[i]) = kr[i];
+                // partner exchange (quad_perm [1,0,3,2]): the even lane assembles dims 0-3, the odd one 4-7
+                const int s0 = odd_lane ? vr[i][0] : vr[i][2], s1 = odd_lane ? vr[i][1] : vr[i][3];
+                const int r0 = __builtin_amdgcn_update_dpp(0, s0, 0xB1, 0xf, 0xf, true);
+                const int r1 = __builtin_amdgcn_update_dpp(0, s1, 0xB1, 0xf, 0xf, true);
+                const uint32_t lo0 = odd_lane ? (uint32_t)r0 : (uint32_t)vr[i][0], lo1 = odd_lane ? (uint32_t)r1 : (uint32_t)vr[i][1];
+                const uint32_t hi0 = odd_lane ? (uint32_t)vr[i][2] : (uint32_t)r0, hi1 = odd_lane ? (uint32_t)vr[i][3] : (uint32_t)r1;
+                uint8_t* vp = vt_ + vdst[i];
+                *reinterpret_cast<uint32_t*>(vp) = __builtin_amdgcn_perm(hi0, lo0, 0x05040100u);
+                *reinterpret_cast<uint32_t*>(vp + C::VROWB) = __builtin_amdgcn_perm(hi0, lo0, 0x07060302u);
+                *reinterpret_cast<uint32_t*>(vp + 2 * C::VROWB) = __builtin_amdgcn_perm(hi1, lo1, 0x05040100u);
+                *reinterpret_cast<uint32_t*>(vp + 3 * C::VROWB) = __builtin_amdgcn_perm(hi1, lo1, 0x07060302u);
+            }
+        }
+    };
+
+    // row D of both V images := {1.0, 1.0} in every pair slot (never overwritten by the staging stores)
+    if (tid < 64)
+        *reinterpret_cast<uint32_t*>(smem + 2 * C::KTILE + (tid >> 5) * C::VTILE + D * C::VROWB + (tid & 31) * 4) = 0x3c003c00u;
+    if (nkt > 0) {
+        load_tile(0, krA, vrA);
+        if (nkt > 1) load_tile(1, krB, vrB);
+        store_tile(0, krA, vrA);
+    }
+    __syncthreads();
+    // one key tile; `cur` (LDS buffer) and the register sets are compile-time per call site: the loop below is
+    // unrolled by two so that set A / set B never meet in a phi (the compiler otherwise copies them through
+    // temporaries behind an s_waitcnt vmcnt(0) that exposes the whole global-load latency every tile)
+    auto tile = [&](const int kt, const int cur, int4v (&krL)[C::KPT], int4v (&vrL)[C::KPT], int4v (&krS)[C::KPT],
+                    int4v (&vrS)[C::KPT]) {
+        if (!(ABL & 8) && kt + 2 < nkt) load_tile(kt + 2, krL, vrL);
+        const uint8_t* kt_ = smem + cur * C::KTILE;
+        const uint8_t* vt_ = smem + 2 * C::KTILE + cur * C::VTILE;
+
+        float16v s[2];
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sc][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                const int d0 = ks * 16 + 8 * g;
+                half8 kf = *reinterpret_cast<const half8*>(kt_ + (sc * 32 + l31) * C::KROW + (d0 < D ? d0 : 0) * 2);
+                if (d0 >= D)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kf[e] = (half_t)0.f;
+                if (!(ABL & 4)) s[sc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sc], 0, 0, 0);
+                else s[sc][ks] += (float)kf[0];
+            }
+        }
+        // stage the NEXT tile while the QK^T MFMAs above are in flight: the other LDS buffer has had no reader
+        // since the last barrier, and nothing below depends on these VALU / LDS-write instructions
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 8) && kt + 1 < nkt) store_tile(cur ^ 1, krS, vrS);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt * 64 + 64 > kv_len) {
+#pragma unroll
+            for (int sc = 0; sc < 2; ++sc)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (key >= kv_len) s[sc][r] = -INFINITY;
+                }
+        }
+        float mloc = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        // deferred rescale: move the running max only when a tile max leads it by more than 2^8
+        if (__any((mloc - m_run) * a.c > 8.0f)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * a.c);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * a.c;
+        // exp and P.V per 32-key sub-tile: the exponentials of sub-tile 1 run under the MFMAs of sub-tile 0
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                s[sc][r] = (ABL & 1) ? fmaf(s[sc][r], a.c, -mc) : __builtin_amdgcn_exp2f(fmaf(s[sc][r], a.c, -mc));
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int kk = 2 * sc + k2, rq = 2 * k2;
+                half8 pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pf[e] = (half_t)s[sc][4 * rq + e];
+                    pf[4 + e] = (half_t)s[sc][4 * rq + 4 + e];
+                }
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const half8 vw = *reinterpret_cast<const half8*>(vt_ + vaddr[dt][kk]);
+                    if (!(ABL & 2)) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vw, pf, oacc[dt], 0, 0, 0);
+                    else oacc[dt][kk] += (float)vw[0] * (float)pf[0];
+                }
+            }
+        }
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, 0, krA, vrA, krB, vrB);               // tile kt sits in buffer 0; loads kt+2 -> A, stages kt+1 <- B
+        if (kt + 1 < nkt) tile(kt + 1, 1, krB, vrB, krA, vrA);
+    }
+
+    constexpr int LD_T = D / 32, LD_R = D % 32;
+    constexpr int LD_G = (LD_R >> 2) & 1, LD_REG = (LD_R & 3) + 4 * (LD_R >> 3);
+    float l_run = oacc[LD_T][LD_REG];
+    l_run = __shfl(l_run, l31 + 32 * LD_G);
+    const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
+    if (q_ok) {
+        half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi * a.o_tok_stride + h * D;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = dt * 32 + 8 * rg + 4 * g;
+                if (d < D) {
+                    half4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[dt][rg * 4 + e] * inv);
+                    *reinterpret_cast<half4*>(orow + d) = ov;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+template <int D, int NW>
+static int launch_attn8(const AttnArgs& a, hipStream_t st) {
+    using C = Att8Cfg<D, NW>;
+    auto k = attn_fwd8_kernel<D, NW>;
+    if (D == 72 && NW == 8) {                          // profiling ablations (VQ_ATTN_ABL)
+        static const int abl = getenv("VQ_ATTN_ABL") ? atoi(getenv("VQ_ATTN_ABL")) : 0;
+        if (abl) {
+            auto ka = abl == 1 ? attn_fwd8_kernel<72, 8, 1> : abl == 2 ? attn_fwd8_kernel<72, 8, 2>
+                    : abl == 4 ? attn_fwd8_kernel<72, 8, 4> : abl == 8 ? attn_fwd8_kernel<72, 8, 8>
+                    : abl == 6 ? attn_fwd8_kernel<72, 8, 6> : attn_fwd8_kernel<72, 8, 15>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+            hipLaunchKernelGGL(ka, dim3(8 * ((a.n_seq * a.H + 7) / 8) * ((a.Lq + 255) / 256)), dim3(512), C::LDS, st, a);
+            return vq_check_launch();
+        }
+    }
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);  // once
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    const int nqt = (a.Lq + 32 * NW - 1) / (32 * NW), G = a.n_seq * a.H;
+    dim3 grid(8 * ((G + 7) / 8) * nqt);
+    hipLaunchKernelGGL(k, grid, dim3(64 * NW), C::LDS, st, a);
+    return vq_check_launch();
+}
+
 template <int D>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
+    // second-generation kernel for long key sequences; short ones (cross attention: <= 2 key tiles, where the
+    // per-workgroup prologue dominates) and short query sequences keep the first kernel.  VQ_ATTN_V1 forces it.
+    static const bool old_kernel = getenv("VQ_ATTN_V1") != nullptr;
+    if (!old_kernel && !a.kv_off && a.Lk > 128 && a.Lq >= 96)
+        return a.Lq >= 192 ? launch_attn8<D, 8>(a, st) : launch_attn8<D, 4>(a, st);
     using C = AttCfg<D>;
     auto k = attn_fwd_kernel<D>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
