@@ -411,8 +411,11 @@ struct Att8Cfg {
 };
 
 // ABL (profiling only, wrong results): 1 no exp, 2 no P.V MFMAs, 4 no QK MFMAs, 8 no staging after tile 0
-template <int D, int NW, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_fwd8_kernel(AttnArgs a) {
+// NQ: independent 32-query blocks per wave.  NQ = 2 (with NW = 4: one wave per SIMD, the whole register file)
+// gives the in-order wave two independent MFMA -> softmax -> MFMA chains to interleave, and every K / V^T fragment
+// read from LDS feeds two MFMAs.
+template <int D, int NW, int ABL = 0, int NQ = 1>
+__global__ __launch_bounds__(64 * NW, NQ == 2 ? 1 : 8 / NW) void attn_fwd8_kernel(AttnArgs a) {
     using C = Att8Cfg<D, NW>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_fwd8_kernel(AttnArgs a) 
     // (profiles/r01_hbm_traffic.md), and re-staging K/V cost 50 of 188 us.
     int qt, h, seq;
     {
-        const int nqt = (a.Lq + 32 * NW - 1) / (32 * NW);
+        const int nqt = (a.Lq + 32 * NW * NQ - 1) / (32 * NW * NQ);
         const int G = a.n_seq * a.H;
         const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
         const int q8 = G / 8, r8 = G % 8;
@@ -452,27 +455,31 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_fwd8_kernel(AttnArgs a) 
         kbase = a.k + (long)seq * a.kv_seq_stride + h * D;
         vbase = a.v + (long)seq * a.kv_seq_stride + h * D;
     }
-    const int qi = qt * (32 * NW) + wave * 32 + l31;
-    const bool q_ok = qi < a.Lq;
-    const int qc = q_ok ? qi : a.Lq - 1;
-    const half_t* qrow = a.q + (long)seq * a.q_seq_stride + (long)qc * a.q_tok_stride + h * D;
-
-    half8 qf[C::KS];
+    int qi[NQ];
+    bool q_ok[NQ];
+    half8 qf[NQ][C::KS];
+    float16v oacc[NQ][C::DT];
+    float m_run[NQ];
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-        const int d0 = ks * 16 + 8 * g;
-        if (d0 < D) qf[ks] = *reinterpret_cast<const half8*>(qrow + d0);
-        else
+    for (int nq = 0; nq < NQ; ++nq) {
+        qi[nq] = qt * (32 * NW * NQ) + (wave * NQ + nq) * 32 + l31;
+        q_ok[nq] = qi[nq] < a.Lq;
+        const int qc = q_ok[nq] ? qi[nq] : a.Lq - 1;
+        const half_t* qrow = a.q + (long)seq * a.q_seq_stride + (long)qc * a.q_tok_stride + h * D;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)0.f;
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int d0 = ks * 16 + 8 * g;
+            if (d0 < D) qf[nq][ks] = *reinterpret_cast<const half8*>(qrow + d0);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[nq][ks][e] = (half_t)0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[nq][dt][r] = 0.f;
+        m_run[nq] = -INFINITY;
     }
-
-    float16v oacc[C::DT];
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY;
 
     // V^T fragment addresses: lane = output dim d (row D = the ones row; rows above it are clamped, unused)
     int vaddr[C::DT][4];
@@ -567,11 +574,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_fwd8_kernel(AttnArgs a) 
         const uint8_t* kt_ = smem + cur * C::KTILE;
         const uint8_t* vt_ = smem + 2 * C::KTILE + cur * C::VTILE;
 
-        float16v s[2];
+        float16v s[NQ][2];
 #pragma unroll
         for (int sc = 0; sc < 2; ++sc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[sc][r] = 0.f;
+            for (int nq = 0; nq < NQ; ++nq)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[nq][sc][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
                 const int d0 = ks * 16 + 8 * g;
@@ -579,8 +588,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_fwd8_kernel(AttnArgs a) 
                 if (d0 >= D)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) kf[e] = (half_t)0.f;
-                if (!(ABL & 4)) s[sc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sc], 0, 0, 0);
-                else s[sc][ks] += (float)kf[0];
+#pragma unroll
+                for (int nq = 0; nq < NQ; ++nq) {
+                    if (!(ABL & 4)) s[nq][sc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[nq][ks], s[nq][sc], 0, 0, 0);
+                    else s[nq][sc][ks] += (float)kf[0];
+                }
             }
         }
         // stage the NEXT tile while the QK^T MFMAs above are in flight: the other LDS buffer has had no reader
@@ -590,51 +602,66 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_fwd8_kernel(AttnArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         if (kt * 64 + 64 > kv_len) {
 #pragma unroll
-            for (int sc = 0; sc < 2; ++sc)
+            for (int nq = 0; nq < NQ; ++nq)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 64 + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    if (key >= kv_len) s[sc][r] = -INFINITY;
-                }
+                for (int sc = 0; sc < 2; ++sc)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 64 + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        if (key >= kv_len) s[nq][sc][r] = -INFINITY;
+                    }
         }
-        float mloc = s[0][0];
+        float mc[NQ];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+        for (int nq = 0; nq < NQ; ++nq) {
+            float mloc = s[nq][0][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        // deferred rescale: move the running max only when a tile max leads it by more than 2^8
-        if (__any((mloc - m_run) * a.c > 8.0f)) {
-            const float m_new = fmaxf(m_run, mloc);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * a.c);
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[nq][0][r]);
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[nq][1][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            // deferred rescale: move the running max only when a tile max leads it by more than 2^8
+            if (__any((mloc - m_run[nq]) * a.c > 8.0f)) {
+                const float m_new = fmaxf(m_run[nq], mloc);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f((m_run[nq] - m_use) * a.c);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-            m_run = m_new;
+                for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[nq][dt][r] *= alpha;
+                m_run[nq] = m_new;
+            }
+            mc[nq] = ((m_run[nq] == -INFINITY) ? 0.f : m_run[nq]) * a.c;
         }
-        const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * a.c;
-        // exp and P.V per 32-key sub-tile: the exponentials of sub-tile 1 run under the MFMAs of sub-tile 0
+        // exp and P.V per 32-key sub-tile (and query block): the exponentials of the next piece run under the
+        // MFMAs of the previous one
 #pragma unroll
         for (int sc = 0; sc < 2; ++sc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                s[sc][r] = (ABL & 1) ? fmaf(s[sc][r], a.c, -mc) : __builtin_amdgcn_exp2f(fmaf(s[sc][r], a.c, -mc));
+            for (int nq = 0; nq < NQ; ++nq)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s[nq][sc][r] = (ABL & 1) ? fmaf(s[nq][sc][r], a.c, -mc[nq])
+                                             : __builtin_amdgcn_exp2f(fmaf(s[nq][sc][r], a.c, -mc[nq]));
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 const int kk = 2 * sc + k2, rq = 2 * k2;
-                half8 pf;
+                half8 pf[NQ];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pf[e] = (half_t)s[sc][4 * rq + e];
-                    pf[4 + e] = (half_t)s[sc][4 * rq + 4 + e];
-                }
+                for (int nq = 0; nq < NQ; ++nq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pf[nq][e] = (half_t)s[nq][sc][4 * rq + e];
+                        pf[nq][4 + e] = (half_t)s[nq][sc][4 * rq + 4 + e];
+                    }
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
                     const half8 vw = *reinterpret_cast<const half8*>(vt_ + vaddr[dt][kk]);
-                    if (!(ABL & 2)) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vw, pf, oacc[dt], 0, 0, 0);
-                    else oacc[dt][kk] += (float)vw[0] * (float)pf[0];
+#pragma unroll
+                    for (int nq = 0; nq < NQ; ++nq) {
+                        if (!(ABL & 2)) oacc[nq][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vw, pf[nq], oacc[nq][dt], 0, 0, 0);
+                        else oacc[nq][dt][kk] += (float)vw[0] * (float)pf[nq][0];
+                    }
                 }
             }
         }
@@ -647,34 +674,37 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_fwd8_kernel(AttnArgs a) 
 
     constexpr int LD_T = D / 32, LD_R = D % 32;
     constexpr int LD_G = (LD_R >> 2) & 1, LD_REG = (LD_R & 3) + 4 * (LD_R >> 3);
-    float l_run = oacc[LD_T][LD_REG];
-    l_run = __shfl(l_run, l31 + 32 * LD_G);
-    const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
-    if (q_ok) {
-        half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi * a.o_tok_stride + h * D;
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
+    for (int nq = 0; nq < NQ; ++nq) {
+        float l_run = oacc[nq][LD_T][LD_REG];
+        l_run = __shfl(l_run, l31 + 32 * LD_G);
+        const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
+        if (q_ok[nq]) {
+            half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi[nq] * a.o_tok_stride + h * D;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int d = dt * 32 + 8 * rg + 4 * g;
-                if (d < D) {
-                    half4 ov;
+            for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[dt][rg * 4 + e] * inv);
-                    *reinterpret_cast<half4*>(orow + d) = ov;
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d = dt * 32 + 8 * rg + 4 * g;
+                    if (d < D) {
+                        half4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[nq][dt][rg * 4 + e] * inv);
+                        *reinterpret_cast<half4*>(orow + d) = ov;
+                    }
                 }
-            }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-template <int D, int NW>
+template <int D, int NW, int NQ = 1>
 static int launch_attn8(const AttnArgs& a, hipStream_t st) {
     using C = Att8Cfg<D, NW>;
-    auto k = attn_fwd8_kernel<D, NW>;
-    if (D == 72 && NW == 8) {                          // profiling ablations (VQ_ATTN_ABL)
+    auto k = attn_fwd8_kernel<D, NW, 0, NQ>;
+    if (D == 72 && NW == 8 && NQ == 1) {               // profiling ablations (VQ_ATTN_ABL)
         static const int abl = getenv("VQ_ATTN_ABL") ? atoi(getenv("VQ_ATTN_ABL")) : 0;
         if (abl) {
             auto ka = abl == 1 ? attn_fwd8_kernel<72, 8, 1> : abl == 2 ? attn_fwd8_kernel<72, 8, 2>
@@ -691,7 +721,7 @@ static int launch_attn8(const AttnArgs& a, hipStream_t st) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
     }
-    const int nqt = (a.Lq + 32 * NW - 1) / (32 * NW), G = a.n_seq * a.H;
+    const int nqt = (a.Lq + 32 * NW * NQ - 1) / (32 * NW * NQ), G = a.n_seq * a.H;
     dim3 grid(8 * ((G + 7) / 8) * nqt);
     hipLaunchKernelGGL(k, grid, dim3(64 * NW), C::LDS, st, a);
     return vq_check_launch();
@@ -703,7 +733,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     // per-workgroup prologue dominates) and short query sequences keep the first kernel.  VQ_ATTN_V1 forces it.
     static const bool old_kernel = getenv("VQ_ATTN_V1") != nullptr;
     if (!old_kernel && !a.kv_off && a.Lk > 128 && a.Lq >= 96)
+    {
+        static const bool two = getenv("VQ_ATTN_NQ2") != nullptr;      // measurement switch
+        if (two && a.Lq >= 192) return launch_attn8<D, 4, 2>(a, st);
         return a.Lq >= 192 ? launch_attn8<D, 8>(a, st) : launch_attn8<D, 4>(a, st);
+    }
     using C = AttCfg<D>;
     auto k = attn_fwd_kernel<D>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
