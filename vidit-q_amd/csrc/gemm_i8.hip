@@ -656,7 +656,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
     constexpr int CPR = WTN / 8;                      // 16-byte chunks per slab row
     constexpr int NCH = WTM * CPR;
     const int mrow0 = m0 + wm * WTM, ncol0 = n0 + wn * WTN;
-#pragma unroll 2
+#pragma unroll 6
     for (int c = lane; c < NCH; c += 64) {
         const int row = c / CPR, col = (c % CPR) * 8;
         const int m = mrow0 + row, n = ncol0 + col;

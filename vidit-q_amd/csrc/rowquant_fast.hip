@@ -157,6 +157,100 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// plain per-token quantizer, TWO rows per wave (C % 128 == 0, C <= 1536, no smoothing / added rows).
+// At C = 1152 the one-row-per-wave kernel above is VALU-bound, and half of its VALU work is per ROW, not per
+// element (two DPP reductions, three IEEE divisions for delta / 1/delta / zp, the row-sum reduction), with a
+// quarter of the lanes idle in the last 512-element pass.  Here a half-wave of 32 lanes owns a row (C/32
+// elements per lane, 8-byte coalesced loads), so the per-row sequence runs once for two rows and every lane
+// is busy.
+// ---------------------------------------------------------------------------
+template <int NIT>   // C = 128 * NIT
+__global__ __launch_bounds__(RQF_THREADS) void rowquant_half_kernel(const half_t* __restrict__ x, int8_t* __restrict__ xq,
+                                                                    float* __restrict__ sx, int32_t* __restrict__ zx,
+                                                                    int32_t* __restrict__ R, float* __restrict__ zpf,
+                                                                    int n_tok, int n_bits, int32_t* status) {
+    constexpr int C = 128 * NIT;
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const bool hi = lane >= 32;
+    int tok = (blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)) * 2 + (hi ? 1 : 0);
+    const bool live = tok < n_tok;
+    if (!live) tok = n_tok - 1;                       // odd tail: the upper half re-does the last row, writes nothing
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int cx = (n_bits == 8) ? 128 : 0;
+    const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
+    const half_t* row = x + (size_t)tok * C + hl * 4;
+
+    half4 h[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) h[i] = *reinterpret_cast<const half4*>(row + i * 128);
+    half4 mn = h[0], mx = h[0];
+#pragma unroll
+    for (int i = 1; i < NIT; ++i) {
+        mn = __builtin_elementwise_min(mn, h[i]);
+        mx = __builtin_elementwise_max(mx, h[i]);
+    }
+    float vmin = fminf(fminf((float)mn[0], (float)mn[1]), fminf((float)mn[2], (float)mn[3]));
+    float vmax = fmaxf(fmaxf((float)mx[0], (float)mx[1]), fmaxf((float)mx[2], (float)mx[3]));
+    // reduce inside each row of 16 lanes by DPP, then combine the two rows of this half
+    VQ_DPP_STEP(float, fminf, vmin, 0xB1);
+    VQ_DPP_STEP(float, fminf, vmin, 0x4E);
+    VQ_DPP_STEP(float, fminf, vmin, 0x141);
+    VQ_DPP_STEP(float, fminf, vmin, 0x140);
+    VQ_DPP_STEP(float, fmaxf, vmax, 0xB1);
+    VQ_DPP_STEP(float, fmaxf, vmax, 0x4E);
+    VQ_DPP_STEP(float, fmaxf, vmax, 0x141);
+    VQ_DPP_STEP(float, fmaxf, vmax, 0x140);
+    {
+        const int bmin = __builtin_bit_cast(int, vmin), bmax = __builtin_bit_cast(int, vmax);
+        const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmin, 0));
+        const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmin, 16));
+        const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmin, 32));
+        const float n3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmin, 48));
+        const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmax, 0));
+        const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmax, 16));
+        const float m2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmax, 32));
+        const float m3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmax, 48));
+        vmin = hi ? fminf(n2, n3) : fminf(n0, n1);
+        vmax = hi ? fmaxf(m2, m3) : fmaxf(m0, m1);
+    }
+    float delta, zp;
+    bool small;
+    vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+    if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
+    const float inv = __fdiv_rn(1.0f, delta);
+    const int izx = (int)zp - cx;
+
+    int8_t* qrow = xq + (size_t)tok * C + hl * 4;
+    uint32_t csum = 0;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float q = rq_round_div((float)h[i][e], inv, delta) + zp;
+            if (qmax != 255.0f) q = __builtin_amdgcn_fmed3f(q, 0.0f, qmax);
+            pk = __builtin_amdgcn_cvt_pk_u8_f32(q, e, pk);
+        }
+        csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
+        if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
+    }
+    int cs = (int)csum;
+    VQ_DPP_STEP(int, vq_addi, cs, 0xB1);
+    VQ_DPP_STEP(int, vq_addi, cs, 0x4E);
+    VQ_DPP_STEP(int, vq_addi, cs, 0x141);
+    VQ_DPP_STEP(int, vq_addi, cs, 0x140);
+    const int c0 = __builtin_amdgcn_readlane(cs, 0), c1 = __builtin_amdgcn_readlane(cs, 16);
+    const int c2 = __builtin_amdgcn_readlane(cs, 32), c3 = __builtin_amdgcn_readlane(cs, 48);
+    const int rs = (hi ? c2 + c3 : c0 + c1) - cx * C;
+    if (hl == 0 && live) {
+        sx[tok] = delta;
+        zx[tok] = izx;
+        R[tok] = rs - C * izx;
+        if (zpf) zpf[tok] = zp;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // LayerNorm(no affine) + AdaLN modulate + NOUT smoothed quantizers, B == 1 per token row
 // (rows of different batch samples are independent here because every row gets its own scale
 //  only when B == 1; the host dispatches B > 1 to the generic kernel)
@@ -275,6 +369,107 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_fast_kernel(
     }
 }
 
+// LN + modulate + ONE un-smoothed quantizer, two rows per wave (same reasoning as rowquant_half_kernel; this
+// kernel has five per-row reductions and four IEEE divisions / a square root per row).
+#define RQH_REDUCE2(T_, OP_, v_)                                                                        \
+    {                                                                                                   \
+        VQ_DPP_STEP(T_, OP_, v_, 0xB1);                                                                 \
+        VQ_DPP_STEP(T_, OP_, v_, 0x4E);                                                                 \
+        VQ_DPP_STEP(T_, OP_, v_, 0x141);                                                                \
+        VQ_DPP_STEP(T_, OP_, v_, 0x140);                                                                \
+        const int b_ = __builtin_bit_cast(int, v_);                                                     \
+        const T_ r0_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 0));                        \
+        const T_ r1_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 16));                       \
+        const T_ r2_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 32));                       \
+        const T_ r3_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 48));                       \
+        v_ = hi ? OP_(r2_, r3_) : OP_(r0_, r1_);                                                        \
+    }
+template <int NIT>
+__global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
+    const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
+    int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R, int n_tok,
+    int n_bits, int32_t* status) {
+    constexpr int C = 128 * NIT;
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const bool hi = lane >= 32;
+    int tok = (blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)) * 2 + (hi ? 1 : 0);
+    const bool live = tok < n_tok;
+    if (!live) tok = n_tok - 1;
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int cx = (n_bits == 8) ? 128 : 0;
+    const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
+    const float invC = 1.0f / (float)C;
+    const half_t* row = x + (size_t)tok * C + hl * 4;
+
+    float v[NIT][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const half4 h = *reinterpret_cast<const half4*>(row + i * 128);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[i][e] = (float)h[e];
+            sum += v[i][e];
+        }
+    }
+    RQH_REDUCE2(float, vq_addf, sum)
+    const float mu = sum * invC;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mu;
+            sq += d * d;
+        }
+    RQH_REDUCE2(float, vq_addf, sq)
+    const float rstd = __fdiv_rn(1.0f, __fsqrt_rn(sq * invC + ln_eps));
+
+    float vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const float4v sc = *reinterpret_cast<const float4v*>(scale + i * 128 + hl * 4);
+        const float4v sh = *reinterpret_cast<const float4v*>(shift + i * 128 + hl * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = (v[i][e] - mu) * rstd;
+            const float u = y * (1.0f + sc[e]) + sh[e];
+            v[i][e] = u;
+            vmin = fminf(vmin, u);
+            vmax = fmaxf(vmax, u);
+        }
+    }
+    RQH_REDUCE2(float, fminf, vmin)
+    RQH_REDUCE2(float, fmaxf, vmax)
+    float delta, zp;
+    bool small;
+    vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+    if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
+    const float inv = __fdiv_rn(1.0f, delta);
+    const int izx = (int)zp - cx;
+    int8_t* qrow = xq + (size_t)tok * C + hl * 4;
+    uint32_t csum = 0;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float q = rq_round_div(v[i][e], inv, delta) + zp;
+            if (qmax != 255.0f) q = __builtin_amdgcn_fmed3f(q, 0.0f, qmax);
+            pk = __builtin_amdgcn_cvt_pk_u8_f32(q, e, pk);
+        }
+        csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
+        if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
+    }
+    int cs = (int)csum;
+    RQH_REDUCE2(int, vq_addi, cs)
+    if (hl == 0 && live) {
+        sx[tok] = delta;
+        zx[tok] = izx;
+        R[tok] = cs - cx * C - C * izx;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host dispatch (called from the C ABI entry points in rowquant.hip)
 // ---------------------------------------------------------------------------
@@ -297,8 +492,20 @@ bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, cons
                       int32_t* zx, int32_t* R, float* zpf, int n_tok, int C, int Kp, int n_bits, int32_t* status,
                       hipStream_t st) {
     if (C > 4608 || Kp > 4608) return false;
-    dim3 grid((n_tok + RQF_WAVES - 1) / RQF_WAVES);
     const bool hs = s != nullptr, ha = add_rows != nullptr;
+    if (!hs && !ha && C % 128 == 0 && Kp == C && (C == 1152 || C == 1024 || C == 1280 || C == 768) && n_tok >= 2) {
+        dim3 g2((n_tok + 2 * RQF_WAVES - 1) / (2 * RQF_WAVES));
+#define RQH_GO(N_) hipLaunchKernelGGL((rowquant_half_kernel<N_>), g2, dim3(RQF_THREADS), 0, st, x, xq, sx, zx, R, zpf, n_tok, n_bits, status)
+        switch (C / 128) {
+            case 6: RQH_GO(6); break;
+            case 8: RQH_GO(8); break;
+            case 9: RQH_GO(9); break;
+            default: RQH_GO(10); break;
+        }
+#undef RQH_GO
+        return true;
+    }
+    dim3 grid((n_tok + RQF_WAVES - 1) / RQF_WAVES);
     if (Kp <= 512) launch_rq<1>(hs, ha, grid, st, x, add_rows, add_div, s, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
     else if (Kp <= 1536) launch_rq<3>(hs, ha, grid, st, x, add_rows, add_div, s, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
     else launch_rq<9>(hs, ha, grid, st, x, add_rows, add_div, s, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
@@ -325,6 +532,20 @@ bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float 
                  const float* const* s, int8_t* const* xq, float* const* sx, int32_t* const* zx, int32_t* const* R,
                  half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
     if (Kp > 1536) return false;
+    if (n_out == 1 && !(s && s[0]) && !xm && Kp == C && (C == 1152 || C == 1024 || C == 1280 || C == 768) && n_tok >= 2) {
+        dim3 g2((n_tok + 2 * RQF_WAVES - 1) / (2 * RQF_WAVES));
+#define LNH_GO(N_)                                                                                              \
+    hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps,  \
+                       xq[0], sx[0], zx[0], R[0], n_tok, n_bits, status)
+        switch (C / 128) {
+            case 6: LNH_GO(6); break;
+            case 8: LNH_GO(8); break;
+            case 9: LNH_GO(9); break;
+            default: LNH_GO(10); break;
+        }
+#undef LNH_GO
+        return true;
+    }
     LnqFastOut o;
     for (int j = 0; j < 3; ++j) {
         const bool on = j < n_out;
