@@ -79,6 +79,16 @@ int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, con
                 const float* delta_in, const float* zp_in, int n_param,
                 int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
 
+/* GELU(tanh) + x / s + per-token dynamic quantizer in ONE pass over x [1, n_tok, C] fp16.
+ * Replaces, for the second MLP Linear: Mlp.act (nn.GELU(approximate="tanh"), t2v/opensora/models/layers/blocks.py:27,
+ * applied to the fc1 output) followed by the fc2 activation quantizer (qdiff/models/quant_layer.py:136-160 +
+ * qdiff/quantizer/dynamic_quantizer.py:16-45).  The fc1 GEMM is then launched with VQ_EPI_NONE: the activation's
+ * exp/rcp run under this HBM-bound kernel instead of the MFMA-bound GEMM epilogue.  GELU output is rounded to fp16
+ * before quantization (the activation dtype of the reference pipeline).  B must be 1 (VQ_EUNSUP otherwise: token
+ * scales shared over a batch need the two-pass generic kernel).  Outputs as vq_rowquant. */
+int vq_gelu_rowquant(const void* x, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, int B, int n_tok,
+                     int C, int Kp, int n_bits, int32_t* status, void* stream);
+
 /* Same, fused with LayerNorm(eps, no affine) + AdaLN modulate:
  *   x_m = LN(x) * (1 + scale[b]) + shift[b]       (stdit.py:100-103,124)
  * shift/scale: fp32 [B, C] (already scale_shift_table + t0 chunk).

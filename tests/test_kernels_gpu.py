@@ -336,3 +336,25 @@ def test_adaln_table_and_cfg_ddim(ops, dev):
     e2 = (torch.tensor(A) * x - x0) / torch.tensor(Bc)
     ref = x0 * torch.sqrt(torch.tensor(abp)) + torch.sqrt(torch.tensor(1 - abp)) * e2
     assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,smooth", [(4608, False), (1152, True), (320, False)])
+def test_gelu_rowquant_matches_gelu_then_rowquant(ops, dev, C, smooth):
+    """vq_gelu_rowquant = nn.GELU(approximate='tanh') (fp16 result) followed by the per-token quantizer: codes and
+    row terms bit-identical to vq_rowquant applied to the separately computed fp16 activation, except where the
+    kernel's rcp/exp2 GELU and torch's differ in the last fp16 ulp (<= 1 code step, < 1 % of elements)."""
+    h = h16(1, 300, C, scale=2.0, seed=C).to(dev)
+    s = (torch.rand(C, generator=torch.Generator().manual_seed(1)) + 0.5).float().to(dev) if smooth else None
+    qa = ops.gelu_rowquant(h, s=s)
+    act = torch.nn.functional.gelu(h.float(), approximate="tanh").half()
+    qb = ops.rowquant(act, s=s)
+    same = (qa.xq == qb.xq).float().mean().item()
+    assert same > 0.99
+    assert (qa.xq.int() - qb.xq.int()).abs().max().item() <= 1
+    assert torch.allclose(qa.sx, qb.sx, rtol=2e-3)
+    # and against the fp32 oracle chain gelu -> x/s -> fake-quant -> dequant
+    deq = (qa.xq[:, :C].float() - qa.zx[:, None].float()) * qa.sx[:, None]
+    ref = torch.nn.functional.gelu(h[0].float(), approximate="tanh")
+    if smooth:
+        ref = ref / s
+    assert rel_l2(deq.cpu(), ref.cpu()) < 1e-2      # 8-bit quantization noise itself

@@ -21,3 +21,5 @@ t3 = timeit(lambda: ops.ln_modulate_rowquant(x, sh, sh), iters=50)
 print("VQ_RQ_GRID=%s  rowquant C1152 %.1f us (%.2f TB/s)  C4608 %.1f us (%.2f TB/s)  ln_mod_quant %.1f us (%.2f TB/s)" % (
     os.environ.get("VQ_RQ_GRID", "default"), t1 * 1e6, M * 1152 * 3 / t1 / 1e12, t2 * 1e6, M * 4608 * 3 / t2 / 1e12,
     t3 * 1e6, M * 1152 * 3 / t3 / 1e12))
+t4 = timeit(lambda: ops.gelu_rowquant(x4), iters=50)
+print("gelu_rowquant C4608 %.1f us (%.2f TB/s)" % (t4 * 1e6, M * 4608 * 3 / t4 / 1e12))

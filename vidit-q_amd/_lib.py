@@ -21,6 +21,7 @@ SIGNATURES = {
     "vq_version": (_i, []),
     "vq_strerror": (C.c_char_p, [_i]),
     "vq_last_hip_error": (_i, []),
+    "vq_gelu_rowquant": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "vq_rowquant": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                          _i, _i, _i, _i, _i, _vp, _vp]),
     "vq_ln_modulate_rowquant": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,

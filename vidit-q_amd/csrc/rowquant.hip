@@ -358,6 +358,21 @@ extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int a
     return vq_check_launch();
 }
 
+bool vq_gelu_rowquant_fast(const half_t* x, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, int n_tok,
+                           int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
+
+extern "C" int vq_gelu_rowquant(const void* x, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, int B,
+                                int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream) {
+    if (!x || !xq || !sx || !zx || !R) return VQ_EINVAL;
+    if (B <= 0 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
+    if (C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
+    if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
+    if (B != 1) return VQ_EUNSUP;   // batch-shared token scales: use the GEMM's GELU epilogue + vq_rowquant
+    if (!vq_gelu_rowquant_fast((const half_t*)x, s, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
+        return VQ_ESHAPE;
+    return vq_check_launch();
+}
+
 extern "C" int vq_ln_modulate_rowquant(const void* x, const float* shift, const float* scale, float ln_eps, int n_out,
                                        const float* const* s, int8_t* const* xq, float* const* sx,
                                        int32_t* const* zx, int32_t* const* R, void* xm_out, int B, int n_tok, int C,

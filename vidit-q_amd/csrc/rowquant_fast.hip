@@ -20,6 +20,12 @@
 // kept minimal: the row's own min/max defines delta, hence |x/delta| <= 255 (no magnitude guard needed here),
 // the rounding-boundary guard is one subtract + one compare, and for 8-bit codes v_cvt_pk_u8_f32 itself
 // saturates to [0, 255] (no clamp instruction).
+__device__ __forceinline__ float rq_gelu_tanh(float x) {
+    // nn.GELU(approximate='tanh') = x * sigmoid(2u), u = sqrt(2/pi)(x + 0.044715 x^3)  (same form as gemm_i8.hip)
+    const float w = x * fmaf(x * x, -0.044715f * 2.302208198f, -2.302208198f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
+}
+
 __device__ __forceinline__ float rq_round_div(float x, float inv, float delta) {
     const float t = x * inv;
     float r = rintf(t);
@@ -56,7 +62,7 @@ __device__ __forceinline__ uint32_t rq_quant8(const float v[8], float inv, float
 // ---------------------------------------------------------------------------
 // plain per-token quantizer, B == 1
 // ---------------------------------------------------------------------------
-template <int MAXCH, bool HAS_S, bool HAS_ADD>
+template <int MAXCH, bool HAS_S, bool HAS_ADD, bool GELU = false>
 __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
     const half_t* __restrict__ x, const half_t* __restrict__ add_rows, int add_div, const float* __restrict__ s,
     int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R,
@@ -73,7 +79,14 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int c0 = lane * 8 + i * 512;
-        if (c0 < C) h[i] = *reinterpret_cast<const half8*>(row + c0);
+        if (c0 < C) {
+            h[i] = *reinterpret_cast<const half8*>(row + c0);
+            if constexpr (GELU) {   // act(fc1 output) applied here, under the HBM stream, instead of in the GEMM epilogue;
+                                    // rounded to fp16 as the activation the reference stores between the two Linears
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[i][e] = (half_t)rq_gelu_tanh((float)h[i][e]);
+            }
+        }
     }
     float vmin, vmax;
     if constexpr (!HAS_S && !HAS_ADD) {
@@ -526,6 +539,21 @@ static void launch_lnq(int n_out, dim3 grid, hipStream_t st, const half_t* x, co
     else
         hipLaunchKernelGGL((ln_modulate_rowquant_fast_kernel<MAXCH, 3>), grid, block, 0, st, x, shift, scale, eps, o,
                            xm, n_tok, C, Kp, n_bits, status);
+}
+
+// GELU(tanh) + (x / s) + per-token quantizer: mlp.act + the activation quantizer of mlp.fc2 in one pass
+bool vq_gelu_rowquant_fast(const half_t* x, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, int n_tok,
+                           int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+    if (C > 4608 || Kp > 4608) return false;
+    dim3 grid((n_tok + RQF_WAVES - 1) / RQF_WAVES), block(RQF_THREADS);
+#define RQG_GO(M_, S_)                                                                                            \
+    hipLaunchKernelGGL((rowquant_fast_kernel<M_, S_, false, true>), grid, block, 0, st, x, (const half_t*)nullptr, 1, s, \
+                       xq, sx, zx, R, (float*)nullptr, n_tok, C, Kp, n_bits, status)
+    if (Kp <= 512) { if (s) RQG_GO(1, true); else RQG_GO(1, false); }
+    else if (Kp <= 1536) { if (s) RQG_GO(3, true); else RQG_GO(3, false); }
+    else { if (s) RQG_GO(9, true); else RQG_GO(9, false); }
+#undef RQG_GO
+    return true;
 }
 
 bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float eps, int n_out,

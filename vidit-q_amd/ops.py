@@ -118,6 +118,24 @@ def rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
     return QAct(xq, sx, zx, R, Cc, n_bits, zpf)
 
 
+def gelu_rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
+                  status: Optional[torch.Tensor] = None) -> QAct:
+    """GELU(tanh) then the per-token quantizer of x [1, n_tok, C] fp16 (the fc1 -> act -> fc2-quantizer hand-over)."""
+    _req(x, torch.float16, "x")
+    B, n_tok, Cc = x.shape
+    Kp = pad128(Cc)
+    dev = x.device
+    xq = torch.empty((n_tok, Kp), dtype=torch.int8, device=dev)
+    sx = torch.empty(n_tok, dtype=torch.float32, device=dev)
+    zx = torch.empty(n_tok, dtype=torch.int32, device=dev)
+    R = torch.empty(n_tok, dtype=torch.int32, device=dev)
+    if s is not None:
+        _req(s, torch.float32, "s")
+    check(_L().vq_gelu_rowquant(_p(x), _p(s), _p(xq), _p(sx), _p(zx), _p(R), B, n_tok, Cc, Kp, n_bits, _p(status),
+                                _stream()), "vq_gelu_rowquant")
+    return QAct(xq, sx, zx, R, Cc, n_bits, None)
+
+
 def ln_modulate_rowquant(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-6,
                          smooth: Sequence[Optional[torch.Tensor]] = (None,), n_bits: int = 8,
                          status: Optional[torch.Tensor] = None, want_xm: bool = False):

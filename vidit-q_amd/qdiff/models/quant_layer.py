@@ -221,6 +221,14 @@ class QuantLayer(nn.Module):
         return ops.rowquant(x3, n_bits=aq.n_bits, s=s, add_rows=add_rows, add_div=add_div,
                             delta=aq.delta.float(), zp=aq.zero_point.float())
 
+    def quantize_gelu_input(self, h3: torch.Tensor, s: Optional[torch.Tensor]) -> Optional[ops.QAct]:
+        """act(GELU tanh) + this layer's activation quantizer in one pass over the PRE-activation ``h3`` [1, n, K];
+        None when the one-pass kernel does not apply (batch-shared scales, static grids): the caller then asks the
+        producing GEMM for its GELU epilogue and calls :meth:`quantize_input`."""
+        if h3.shape[0] != 1 or not isinstance(self.act_quantizer, DynamicActQuantizer):
+            return None
+        return ops.gelu_rowquant(h3, n_bits=self.act_quantizer.n_bits, s=s, status=self.status)
+
     # With weight_quant off and smooth_quant on, QuantLayer multiplies the FP weight by the smoothing vector
     # (quant_layer.py:188-189: (x/s)(W*s)^T = x W^T); the STDiT attention subclasses do NOT
     # (stdit_quant_layer.py:90,181,298: (x/s) W^T) - kept as released, see fp_weight_smoothed there.

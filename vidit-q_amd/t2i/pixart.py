@@ -158,9 +158,12 @@ class PixArtMSBlock(nn.Module):
         r, s = sv(fc1)
         qa = ops.ln_modulate_rowquant(x3, shift_mlp, scale_mlp, 1e-6, smooth=[s], n_bits=fc1.act_quantizer.n_bits,
                                       status=st)[0]
-        h = ops.gemm_i8(qa, fc1.packed_weight(r, s), bias=fc1.bias_f32(), epilogue=ops.EPI_GELU)
+        from ..t2v.stdit import _GELU_QUANT
+        one_pass = _GELU_QUANT and B == 1 and isinstance(fc2.act_quantizer, DynamicActQuantizer)   # see t2v/stdit.py
+        h = ops.gemm_i8(qa, fc1.packed_weight(r, s), bias=fc1.bias_f32(), epilogue=ops.EPI_NONE if one_pass else ops.EPI_GELU)
         r, s = sv(fc2)
-        ops.gemm_i8(fc2.quantize_input(h.view(B, N, -1), s), fc2.packed_weight(r, s), bias=fc2.bias_f32(), out=x2,
+        qa = fc2.quantize_gelu_input(h.view(B, N, -1), s) if one_pass else fc2.quantize_input(h.view(B, N, -1), s)
+        ops.gemm_i8(qa, fc2.packed_weight(r, s), bias=fc2.bias_f32(), out=x2,
                     epilogue=ops.EPI_GATE_RESID, resid=x2, gate=gate_mlp, rows_per_gate=N)
         return x2
 

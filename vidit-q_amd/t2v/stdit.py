@@ -224,6 +224,12 @@ class MultiHeadCrossAttention(nn.Module):
 
 
 # --------------------------------------------------------------------------- block
+# GELU inside fc2's quantizer pass (vq_gelu_rowquant) instead of the fc1 GEMM epilogue: fc1 -22 us, quantizer +13 us
+# in isolation, but 1 % SLOWER in the two-stream step (the quantizer's extra VALU lands where the other stream's
+# HBM-bound kernels run; the epilogue's lands under them).  Off unless VQ_GELU_QUANT is set.
+_GELU_QUANT = bool(__import__('os').environ.get('VQ_GELU_QUANT'))
+
+
 class STDiTBlock(nn.Module):
     def __init__(self, hidden_size, num_heads, d_s=None, d_t=None, mlp_ratio=4.0, **unused):
         super().__init__()
@@ -373,8 +379,10 @@ class STDiTBlock(nn.Module):
         fc1, fc2 = self.mlp.fc1, self.mlp.fc2
         qa = ops.ln_modulate_rowquant(x3, shift_mlp, scale_mlp, 1e-6, smooth=[svec(fc1)],
                                       n_bits=fc1.act_quantizer.n_bits, status=st)[0]
-        h = ops.gemm_i8(qa, fc1.packed_weight(r, svec(fc1)), bias=fc1.bias_f32(), epilogue=ops.EPI_GELU)
-        qa = fc2.quantize_input(h.view(B, N, -1), svec(fc2))
+        one_pass = B == 1 and isinstance(fc2.act_quantizer, DynamicActQuantizer) and _GELU_QUANT
+        h = ops.gemm_i8(qa, fc1.packed_weight(r, svec(fc1)), bias=fc1.bias_f32(),
+                        epilogue=ops.EPI_NONE if one_pass else ops.EPI_GELU)
+        qa = fc2.quantize_gelu_input(h.view(B, N, -1), svec(fc2)) if one_pass else fc2.quantize_input(h.view(B, N, -1), svec(fc2))
         ops.gemm_i8(qa, fc2.packed_weight(r, svec(fc2)), bias=fc2.bias_f32(), out=x2,
                     epilogue=ops.EPI_GATE_RESID, resid=x2, gate=gate_mlp, rows_per_gate=N)
         return x2
