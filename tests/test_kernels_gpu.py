@@ -138,7 +138,7 @@ def _oracle_linear(x, W, b, w_bits, a_bits, s=None):
                            smooth=None if s is None else s.reshape(1, -1))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 20, 21])
 @pytest.mark.parametrize("M,N,K", [(64, 48, 96), (300, 292, 128), (512, 576, 1152), (130, 1152, 4608)])
 def test_gemm_w8a8_vs_oracle(ops, dev, variant, M, N, K):
     x = h16(1, M, K, scale=1.5, seed=M + K)

@@ -531,11 +531,11 @@ __device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int
     }
     return c;
 }
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
 __device__ __forceinline__ void ring_park_col_params(const ColParams& c, uint8_t* smem) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     static_assert(BN <= NT, "one channel per thread");
-    constexpr int PAR_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16);
+    constexpr int PAR_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD);
     if ((int)threadIdx.x < BN) {
         reinterpret_cast<float*>(smem + PAR_OFF)[threadIdx.x] = c.sw;
         reinterpret_cast<int*>(smem + PAR_OFF)[BN + threadIdx.x] = c.nzw;
@@ -562,11 +562,11 @@ __device__ __forceinline__ RowParams ring_load_row_params(const GemmArgs& a, int
     }
     return r;
 }
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
 __device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t* smem) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     static_assert(BM <= NT, "one token row per thread");
-    constexpr int ROW_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 16 * BN;
+    constexpr int ROW_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD) + 16 * BN;
     static_assert(ROW_OFF + 12 * BM <= 163840, "LDS budget");
     if ((int)threadIdx.x < BM) {
         reinterpret_cast<float*>(smem + ROW_OFF)[threadIdx.x] = r.sx;
@@ -577,17 +577,17 @@ __device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t
 
 // Stage both parameter blocks (called once all fragment reads of the main loop are issued; the blocks lie
 // past the end of every ring, so no barrier is needed before writing them, only before reading them).
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
 __device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* smem, int m0, int n0) {
     const ColParams colp = ring_load_col_params<BN>(a, n0);
     const RowParams rowp = ring_load_row_params<BM>(a, m0);
-    ring_park_col_params<BM, BN, WAVES_M, WAVES_N>(colp, smem);
-    ring_park_row_params<BM, BN, WAVES_M, WAVES_N>(rowp, smem);
+    ring_park_col_params<BM, BN, WAVES_M, WAVES_N, PAD>(colp, smem);
+    ring_park_row_params<BM, BN, WAVES_M, WAVES_N, PAD>(rowp, smem);
 }
 
 // Shared epilogue of the LDS-DMA ring kernels (called after a workgroup barrier; uses all of smem; the
 // parameter block must have been staged by ring_stage_params and made visible by that barrier).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16>
 __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                                               int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
                                               long long* ts = nullptr) {
@@ -604,7 +604,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
     // parks its 64 x WTN fp16 sub-tile in its own LDS slab (row stride ROWB), then re-reads it as 16-byte
     // chunks in row-major order, so one store instruction covers contiguous WTN*2-byte runs of ~3.5 rows;
     // the residual / gate operands of the fused adds are read with the same coalesced pattern.
-    constexpr int ROWB = WTN * 2 + 16;                // slab row stride in bytes (16 B aligned; 2-way write conflicts)
+    constexpr int ROWB = WTN * 2 + PAD;               // slab row stride in bytes (16 B aligned; PAD 16: 2-way write conflicts)
     constexpr int SLAB = WTM * ROWB;
     constexpr int PAR_OFF = NW * SLAB;                // per-channel parameter block behind the slabs
     const float* l_sw = reinterpret_cast<const float*>(smem + PAR_OFF);
@@ -1332,6 +1332,177 @@ static int launch_gemm_pp(const GemmArgs& a, hipStream_t st) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Half-CU kernel (variant 20): a 4-wave workgroup, 256 x 144 tile, <= 80 KB of LDS and <= 256 VGPRs, so that
+// TWO workgroups - normally one from each of the two streams a denoising step runs on (cond / uncond) - share a
+// CU and one's prologue / dequant / store phases (40 % of a tile's time in variant 11, during which the matrix
+// pipes idle) run under the other's main loop.  Each wave owns 64 tokens x all 144 channels of the tile, so the
+// TOKEN operand is private to a wave: its fragments go straight from global/L2 into registers (both 64-byte
+// halves of a line are requested back to back, one tile ahead), and only the shared WEIGHT operand travels
+// through LDS (full-line LDS-DMA stages of 144 x 128 B, ring of 3).  Per 64-byte k-step a workgroup moves
+// 16 KB + 9 KB through the CU's texture path: two of them need 50 KB per 1152 MFMA cycles = 43 B/clk of ~60.
+// ---------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_i8_half_kernel(GemmArgs a, int tiles_per_wg) {
+    constexpr int BM = 256, BN = 144, NW = 4, TM = 4, TN = 9, PAD = 0;
+    constexpr int WS = BN * 128;                      // one weight stage (128 bytes of k per channel row)
+    constexpr int NST = 3;
+    constexpr int WPIECES = WS / 1024;                // 18
+    constexpr int PPW = (WPIECES + NW - 1) / NW;      // 5
+    constexpr int PLAST = WPIECES - (PPW - 1) * NW;   // waves < PLAST issue PPW pieces
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool full_wave = wave < PLAST;
+    const int frow = lane & 15, fc = lane >> 4;
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    const int T = MT * NTl;
+    const int nkt = a.Kp / 128;
+    const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
+    // weight fragment offsets inside a stage (k-step h: chunk 4h + fc, XOR (row >> 1) & 7)
+    const int wf0 = frow * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int wf1 = wf0 ^ 64;
+
+    for (int it = 0; it < tiles_per_wg; ++it) {
+        const int vb = blockIdx.x + it * gridDim.x;   // virtual block id in the XCD-aware tile order
+        if (vb >= T) break;
+        int mt_, nt_;
+        xcd_tile(vb, MT, NTl, mt_, nt_);
+        const int m0 = mt_ * BM, n0 = nt_ * BN;
+
+        uint32_t woff[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + i * NW;
+            const int r = p * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gn = n0 + r;
+            gn = gn < a.N ? gn : a.N - 1;
+            woff[i] = (uint32_t)gn * (uint32_t)a.Kp + c * 16;
+        }
+        auto issue_w = [&](int stage, int kt) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int p = wave + i * NW;
+                if (p < WPIECES)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.wq + woff[i] + kt * 128),
+                                                     (void __attribute__((address_space(3)))*)(smem + stage * WS + p * 1024),
+                                                     16, 0, 0);
+            }
+        };
+        // token fragments: lane (frow, fc) of token tile i reads 16 bytes at row m0 + 64 wave + 16 i + frow
+        uint32_t xoff[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int gm = m0 + wave * 64 + i * 16 + frow;
+            gm = gm < a.M ? gm : a.M - 1;
+            xoff[i] = (uint32_t)gm * (uint32_t)a.Kp + fc * 16;
+        }
+        // X(kt, h) lives in xh[h]; each half is re-loaded for the next tile right after its last use (one k-step
+        // ahead of its next use; the h = 1 request hits the line the h = 0 request brought into L1)
+        auto load_x = [&](int kt, int h, int4v (&xr)[TM]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xr[i] = *reinterpret_cast<const int4v*>(xbase + xoff[i] + kt * 128 + h * 64);
+        };
+
+        int4v acc[TN][TM];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
+
+        int4v xh0[TM], xh1[TM];
+        // prologue: W(0), W(1) by DMA, X(0) to registers
+        issue_w(0, 0);
+        if (nkt > 1) issue_w(1, 1);
+        load_x(0, 0, xh0);
+        load_x(0, 1, xh1);
+        if (nkt > 1) {
+            // W(0) must have landed: everything issued after it may still fly (W(1) pieces + 8 X loads)
+            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW + 8) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1 + 8) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int st = kt % NST;
+            const uint8_t* ws = smem + st * WS;
+            const bool more1 = kt + 1 < nkt, more2 = kt + 2 < nkt;
+            __builtin_amdgcn_sched_barrier(0);
+            if (more2) issue_w((kt + 2) % NST, kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            int4v w[3];
+            w[0] = *reinterpret_cast<const int4v*>(ws + wf0);
+            w[1] = *reinterpret_cast<const int4v*>(ws + wf0 + 16 * 128);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (j + 2 < TN) w[(j + 2) % 3] = *reinterpret_cast<const int4v*>(ws + (h ? wf1 : wf0) + (j + 2) * 16 * 128);
+                    else if (h == 0) w[(j + 2) % 3] = *reinterpret_cast<const int4v*>(ws + wf1 + (j + 2 - TN) * 16 * 128);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[j % 3], h ? xh1[i] : xh0[i], acc[j][i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more1) {
+                    if (h == 0) load_x(kt + 1, 0, xh0);
+                    else load_x(kt + 1, 1, xh1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // W(kt+1) must be visible before the next tile.  It was issued before X(kt, *) whose data the MFMAs
+            // above have consumed (vmcnt retires in order), so it has landed; the counted wait below states the
+            // requirement anyway: only W(kt+2) [P pieces] and X(kt+1) [8 loads] may still be in flight.
+            if (more1) {
+                if (more2) {
+                    if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW + 8) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1 + 8) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        ring_stage_params<BM, BN, NW, 1, PAD>(a, smem, m0, n0);
+        __syncthreads();
+        ring_epilogue<BM, BN, NW, 1, EPI, PAD>(a, smem, acc, m0, n0);
+        __syncthreads();                                // slabs are re-used as the next tile's weight ring
+    }
+}
+
+static int launch_gemm_half(const GemmArgs& a, hipStream_t st, int persistent) {
+    constexpr size_t LDS = 4 * 64 * (144 * 2) + 16 * 144 + 12 * 256;   // slabs (PAD 0) + parameter blocks = 79,104
+    static_assert(LDS <= 81920 && 3 * 144 * 128 <= 4 * 64 * 288, "two workgroups per CU; ring inside the slab area");
+    const int T = ((a.M + 255) / 256) * ((a.N + 143) / 144);
+    int grid = T, per = 1;
+    if (persistent && T > 256) {                       // one workgroup per CU, the other half of the CU left free
+        grid = 256;
+        per = (T + 255) / 256;
+    }
+#define VQ_HALF(E_)                                                                                              \
+    {                                                                                                           \
+        auto k = gemm_i8_half_kernel<E_>;                                                                       \
+        static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                             \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);        \
+        if (e != hipSuccess) {                                                                                  \
+            g_vq_last_hip_error = (int)e;                                                                       \
+            return VQ_ELAUNCH;                                                                                  \
+        }                                                                                                       \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), LDS, st, a, per);                                          \
+    }
+    switch (a.epilogue) {
+        case VQ_EPI_NONE: VQ_HALF(VQ_EPI_NONE) break;
+        case VQ_EPI_GELU: VQ_HALF(VQ_EPI_GELU) break;
+        case VQ_EPI_GATE_RESID: VQ_HALF(VQ_EPI_GATE_RESID) break;
+        default: VQ_HALF(VQ_EPI_RESID) break;
+    }
+#undef VQ_HALF
+    return vq_check_launch();
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 static int launch_gemm(const GemmArgs& a, int w_bits, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -1416,6 +1587,12 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         case 13:  // ping-pong: SIMD partners alternate MFMA-only and load-only segments
             if (w_bits <= 4) return launch_gemm_pp<256, 288, 4, 2, true>(a, st);
             return launch_gemm_pp<256, 288, 4, 2>(a, st);
+        case 20:  // half-CU workgroups (4 waves, 256 x 144, <= 80 KB LDS), one tile per workgroup
+            if (w_bits <= 4) return VQ_EUNSUP;
+            return launch_gemm_half(a, st, 0);
+        case 21:  // the same, persistent: 256 workgroups walk the tiles (leaves half of every CU to the other stream)
+            if (w_bits <= 4) return VQ_EUNSUP;
+            return launch_gemm_half(a, st, 1);
         case 15:  // ping-pong with ONE barrier per 128-byte stage (roles re-seeded at every stage hand-over)
             if (w_bits <= 4) return launch_gemm_pp<256, 288, 4, 2, true, false>(a, st);
             return launch_gemm_pp<256, 288, 4, 2, false, false>(a, st);
