@@ -28,3 +28,7 @@ o = torch.empty_like(q)
 t = timeit(lambda: ops.attn_fwd(q, kv, kv[:, 1152:], o, 1, 16384, 0, H, D, 16384 * 1152, 1152, 0, 2304, 16384 * 1152, 1152,
                                 kv_off=off), iters=20)
 print("cross 16384 x 120: %.1f us" % (t * 1e6))
+qkv = torch.randn(16384, 3456, generator=g).half().to(dev)
+o = torch.empty((16384, 1152), dtype=torch.float16, device=dev)
+t = timeit(lambda: ops.attn_temporal(qkv, qkv[:, 1152:], qkv[:, 2304:], o, 1, 16, 1024, H, D, 3456, 1152), iters=20)
+print("temporal 1024 x 16: %.1f us  (%.2f TB/s)" % (t * 1e6, 16384 * 1152 * 2 * 4 / t / 1e12))

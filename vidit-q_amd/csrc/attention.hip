@@ -281,17 +281,29 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(TempArgs a) {
     const int nh = (a.H - h0) < 4 ? (a.H - h0) : 4;  // heads present in this quad
 
     // ---- stage Q, K, V rows [2 s][16 t] x [4 heads * D] through LDS (coalesced 16 B chunks) ----
-    for (int c = tid; c < 3 * 32 * SEGCH; c += 256) {
+    // ALL loads of a thread are issued before its first LDS write (constant trip count, registers): with one
+    // load -> wait -> store per iteration the kernel serialised 14 HBM round trips per workgroup
+    constexpr int NCHK = 3 * 32 * SEGCH, NIT = (NCHK + 255) / 256;
+    int4v vals[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int c = tid + i * 256;
         const int ten = c / (32 * SEGCH), rem = c % (32 * SEGCH);
         const int row = rem / SEGCH, ch = rem % SEGCH;
         const int sl = row >> 4, t = row & 15;
-        int4v val = {0, 0, 0, 0};
-        if (t < a.T && s0 + sl < a.S && ch < nh * CHD) {
+        vals[i] = int4v{0, 0, 0, 0};
+        if (c < NCHK && t < a.T && s0 + sl < a.S && ch < nh * CHD) {
             const half_t* base = ten == 0 ? a.q : (ten == 1 ? a.k : a.v);
             const long grow = ((long)b * a.T + t) * a.S + s0 + sl;
-            val = *reinterpret_cast<const int4v*>(base + grow * a.ld_in + h0 * D + ch * 8);
+            vals[i] = *reinterpret_cast<const int4v*>(base + grow * a.ld_in + h0 * D + ch * 8);
         }
-        *reinterpret_cast<int4v*>(smem + ten * TILE + row * RS + ch * 16) = val;
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int c = tid + i * 256;
+        const int ten = c / (32 * SEGCH), rem = c % (32 * SEGCH);
+        const int row = rem / SEGCH, ch = rem % SEGCH;
+        if (c < NCHK) *reinterpret_cast<int4v*>(smem + ten * TILE + row * RS + ch * 16) = vals[i];
     }
     __syncthreads();
     if (wave >= nh) return;
