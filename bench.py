@@ -177,6 +177,25 @@ def main():
             torch.cuda.synchronize()
             ops.GEMM_TIMING = None
         status = qnn.check_status()
+        # extra (NOT the reported value): the same K steps with the step-invariant prompt work hoisted out of the loop
+        # (y_embedder + every block's cross-attention K/V computed once per prompt; bit-identical outputs)
+        cached = None
+        if gs is not None and hasattr(qnn.model, "set_prompt_cache"):
+            qnn.model.set_prompt_cache(True)
+            gs2 = graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
+            gs_keep, gs = gs, gs2
+            for j in range(a.warmup):
+                x, buf = step(j, x, buf)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for j in range(a.warmup, a.warmup + a.steps):
+                x, buf = step(j, x, buf)
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            cached = {"value_this_rank": a.steps / el2, "ms_per_step": el2 / a.steps * 1e3,
+                      "note": "prompt K/V + embedding computed once per prompt instead of once per forward; exact; not the headline"}
+            gs = gs_keep
+            qnn.model.set_prompt_cache(False)
 
     el_t = torch.tensor([el], device=dev, dtype=torch.float64)
     if dist is not None:
@@ -220,6 +239,7 @@ def main():
                                        "DDIM-%d schedule, cfg 4.0, cfg_split, depth %d" % (plan_name, plan_yaml, n_sampling, a.depth),
                            "tokens": 16384, "prompts_in_flight": world, "sharding": "prompt -> rank (no in-step collective)",
                            "status_word": status, "hip_graph": not a.no_graph, "cond_uncond_streams": 1 if (a.one_stream or a.no_graph) else 2},
+                "prompt_invariants_hoisted": cached,
                 "whole_step_int8_frac": 43.87e12 * (a.depth / 28.0) * value / world / PEAK_INT8,
                 "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:

@@ -408,3 +408,26 @@ def test_tiny_pixart_dpm_solver_trajectory(dev, ops):
     out = solver.sample(g["dpm_z"].to(dev), steps=5, order=2, skip_type="time_uniform", method="multistep")
     # 5 guided steps (cfg 4.5 amplifies the cond/uncond difference) on fp16 activations and fp16 timesteps
     assert rel_l2(out.cpu().float(), g["dpm_final"]) < 2e-2
+
+
+def test_prompt_cache_is_exact(dev, ops):
+    """set_prompt_cache: y_embedder / token selection / per-block cross-attention K/V computed once per prompt;
+    outputs bit-identical to the per-forward recomputation, across timesteps and after the prompt changes."""
+    g = load_npz("tiny_stdit_w8a8.npz")
+    qnn = _build(g, dev, 8)
+    x, y, mask = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev)
+    ts = [torch.tensor([v], device=dev) for v in (900, 500, 20)]
+    ref = [qnn(x, t, y[:1], mask=mask).clone() for t in ts]
+    ref_u = qnn(x, ts[1], y[1:], mask=mask).clone()
+    qnn.model.set_prompt_cache(True)
+    for t, r in zip(ts, ref):
+        assert torch.equal(qnn(x, t, y[:1], mask=mask), r)
+    assert len(qnn.model.blocks[0]._kv_cache.d) == 1
+    assert torch.equal(qnn(x, ts[1], y[1:], mask=mask), ref_u)          # another prompt: new cache entry
+    assert torch.equal(qnn(x, ts[1], y[:1], mask=mask), ref[1])
+    y2 = y.clone()
+    y2[:1] *= 0.5                                                        # a changed embedding must not hit the cache
+    out = qnn(x, ts[1], y2[:1], mask=mask)
+    assert not torch.equal(out, ref[1])
+    qnn.model.set_prompt_cache(False)
+    assert torch.equal(qnn(x, ts[1], y2[:1], mask=mask), out)
