@@ -1079,12 +1079,16 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
         }                                                                                                  \
     }
+    // ABL & 32 (experiment): static priority for the later-dispatched half of the waves - measured 12 % SLOWER
+    // main loop (29.7 k vs 26.6 k cycles), so off
+    if ((ABL & 32) != 0 && late) __builtin_amdgcn_s_setprio(1);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1, nxt = cur ^ 1;
         const bool more = kt + 1 < nkt;
         VQ_WIDE_STEP(xa, xb, 0)
         VQ_WIDE_STEP(xb, xa, 1)
     }
+    if ((ABL & 32) != 0) __builtin_amdgcn_s_setprio(0);
 #undef VQ_WIDE_STEP
     if (ts) ts[2] = __builtin_readcyclecounter();
     ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0);
@@ -1602,7 +1606,7 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         default:
             break;
     }
-    if (variant >= 100 && variant < 132 && w_bits > 4) {   // profiling ablations of variant 11 (wrong results)
+    if (variant >= 100 && variant < 164 && w_bits > 4) {   // profiling ablations of variant 11 (wrong results)
 #define VQ_ABL(A)                                                                                               \
     case 100 + A: {                                                                                             \
         auto k = gemm_i8_wide_kernel<256, 288, 4, 2, VQ_EPI_NONE, true, false, A>;                              \
@@ -1625,7 +1629,7 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
             return vq_check_launch();
         }
         switch (variant) {
-            VQ_ABL(1) VQ_ABL(2) VQ_ABL(3) VQ_ABL(4) VQ_ABL(5) VQ_ABL(8) VQ_ABL(9) VQ_ABL(10) VQ_ABL(12) VQ_ABL(13) VQ_ABL(16)
+            VQ_ABL(1) VQ_ABL(2) VQ_ABL(3) VQ_ABL(4) VQ_ABL(5) VQ_ABL(8) VQ_ABL(9) VQ_ABL(10) VQ_ABL(12) VQ_ABL(13) VQ_ABL(16) VQ_ABL(48)
             default: break;
         }
 #undef VQ_ABL
