@@ -48,6 +48,19 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
 
     def forward(self, x):
+        proj = self.proj
+        fp = not (getattr(proj, "weight_quant", False) or getattr(proj, "act_quant", False) or
+                  getattr(proj, "smooth_quant", False))
+        if fp and x.is_cuda:      # kernel == stride: the FP patch embedding is one matmul (see t2v/stdit.py PatchEmbed3D)
+            w_ = getattr(proj, "org_weight", None)
+            w_ = proj.weight if w_ is None else w_
+            b_ = getattr(proj, "org_bias", None) if hasattr(proj, "org_weight") else proj.bias
+            B, Cin, H, W = x.shape
+            ph, pw = self.patch_size
+            xp = x.reshape(B, Cin, H // ph, ph, W // pw, pw).permute(0, 2, 4, 1, 3, 5).reshape(-1, Cin * ph * pw)
+            import torch.nn.functional as F
+            out = F.linear(xp.to(w_.dtype), w_.reshape(w_.shape[0], -1), None if b_ is None else b_.to(w_.dtype))
+            return out.reshape(B, -1, w_.shape[0])
         return self.proj(x).flatten(2).transpose(1, 2)
 
 

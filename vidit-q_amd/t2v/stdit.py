@@ -96,6 +96,22 @@ class PatchEmbed3D(nn.Module):
             x = F.pad(x, (0, 0, 0, self.patch_size[1] - H % self.patch_size[1]))
         if D % self.patch_size[0] != 0:
             x = F.pad(x, (0, 0, 0, 0, 0, self.patch_size[0] - D % self.patch_size[0]))
+        proj = self.proj
+        fp = not (getattr(proj, "weight_quant", False) or getattr(proj, "act_quant", False) or
+                  getattr(proj, "smooth_quant", False))
+        if fp and x.is_cuda:
+            # FP patch embedding (remain_fp.txt keeps it FP): kernel == stride, so the convolution is a
+            # [tokens, Cin*pt*ph*pw] x [that, E] matmul.  MIOpen has no tuned kernel for this Conv3d and runs its
+            # naive one (377 us per forward); the matmul form takes ~10 us.
+            w_ = getattr(proj, "org_weight", None)
+            w_ = proj.weight if w_ is None else w_
+            b_ = getattr(proj, "org_bias", None) if hasattr(proj, "org_weight") else proj.bias
+            B, Cin, D, H, W = x.shape
+            pt, ph, pw = self.patch_size
+            xp = x.reshape(B, Cin, D // pt, pt, H // ph, ph, W // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+            xp = xp.reshape(B * (D // pt) * (H // ph) * (W // pw), Cin * pt * ph * pw)
+            out = F.linear(xp.to(w_.dtype), w_.reshape(w_.shape[0], -1), None if b_ is None else b_.to(w_.dtype))
+            return out.reshape(B, -1, w_.shape[0])
         x = self.proj(x)
         return x.flatten(2).transpose(1, 2)  # BCTHW -> BNC
 
