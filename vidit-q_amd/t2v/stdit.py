@@ -167,6 +167,12 @@ class T2IFinalLayer(nn.Module):
         self.out_channels = out_channels
 
     def forward(self, x, t):
+        if x.is_cuda and x.dtype == torch.float16 and x.dim() == 3 and self.scale_shift_table.dtype == torch.float16:
+            # LayerNorm + modulate in ONE pass of the fused kernel (its modulated fp16 output; the quantized codes it
+            # also produces are not used here) instead of a LayerNorm and two broadcast elementwise launches
+            mod = ops.adaln_table(self.scale_shift_table.detach(), torch.cat([t, t], dim=1).to(torch.float16).contiguous())
+            _, xm = ops.ln_modulate_rowquant(x.contiguous(), mod[0], mod[1], 1e-6, want_xm=True)
+            return self.linear(xm)
         shift, scale = (self.scale_shift_table[None] + t[:, None]).chunk(2, dim=1)
         x = t2i_modulate(self.norm_final(x), shift, scale)
         return self.linear(x)
