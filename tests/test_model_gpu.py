@@ -422,7 +422,7 @@ def test_prompt_cache_is_exact(dev, ops):
     qnn.model.set_prompt_cache(True)
     for t, r in zip(ts, ref):
         assert torch.equal(qnn(x, t, y[:1], mask=mask), r)
-    assert len(qnn.model.blocks[0]._kv_cache.d) == 1
+    assert len(qnn.model.blocks[0]._kv_cache) == 1
     assert torch.equal(qnn(x, ts[1], y[1:], mask=mask), ref_u)          # another prompt: new cache entry
     assert torch.equal(qnn(x, ts[1], y[:1], mask=mask), ref[1])
     y2 = y.clone()

@@ -259,8 +259,8 @@ class PixArtMS(nn.Module):
             m = mask if mask.shape[0] == B else mask.repeat(B // mask.shape[0], 1)
             m = m.reshape(B, -1)
             idx = torch.nonzero(m.reshape(-1) != 0, as_tuple=False).reshape(-1)
-            self._mask_cache = (key, idx, [int(v) for v in m.sum(dim=1).tolist()])
-        _, idx, lens = self._mask_cache
+            self._mask_cache = (key, idx, [int(v) for v in m.sum(dim=1).tolist()], mask)   # mask kept alive
+        _, idx, lens = self._mask_cache[:3]
         return y.squeeze(1).reshape(-1, C).index_select(0, idx).reshape(1, -1, C), lens
 
     def forward(self, x, timestep, y, mask=None, data_info=None, **kwargs):

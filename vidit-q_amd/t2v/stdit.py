@@ -211,19 +211,33 @@ _OFFSETS = {}
 
 
 class _SmallCache:
-    """Last-N cache for step-invariant tensors (prompt embedding, per-block cross-attention K/V)."""
+    """Last-N cache for step-invariant tensors (prompt embedding, per-block cross-attention K/V).  Tensor members of a
+    key are compared by (address, shape, strides, dtype, version); the entry keeps the key tensors alive, so their
+    storage cannot be freed and its address recycled into a false hit while the entry exists."""
 
     def __init__(self, n=8):
-        self.n, self.d = n, {}
+        self.n, self.items = n, []
+
+    @staticmethod
+    def _sig(key):
+        return tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version)
+                     if isinstance(t, torch.Tensor) else t for t in key)
 
     def get(self, key):
-        return self.d.get(key)
+        sig = self._sig(key)
+        for s_, _, val in self.items:
+            if s_ == sig:
+                return val
+        return None
 
     def put(self, key, val):
-        if len(self.d) >= self.n:
-            self.d.pop(next(iter(self.d)))
-        self.d[key] = val
+        if len(self.items) >= self.n:
+            self.items.pop(0)
+        self.items.append((self._sig(key), key, val))
         return val
+
+    def __len__(self):
+        return len(self.items)
 
 
 def seq_offsets(lens, device) -> torch.Tensor:
@@ -413,7 +427,7 @@ class STDiTBlock(nn.Module):
         # function of (y2, packed weight of this time-range / bit width) - computed once, then re-used by every
         # later step (the reference recomputes it per forward with identical results)
         pw_kv = ca.kv_linear.packed_weight(r, svec(ca.kv_linear))
-        kkey = (y2.data_ptr(), y2._version, tuple(y2.shape), pw_kv.wq.data_ptr(), ca.kv_linear.act_quantizer.n_bits)
+        kkey = (y2, pw_kv.wq, ca.kv_linear.act_quantizer.n_bits)
         kv = self._kv_cache.get(kkey) if self.cache_prompt else None
         if kv is None:
             ya = ca.kv_linear.quantize_input(y2.view(1, -1, C), svec(ca.kv_linear))
@@ -533,8 +547,8 @@ class STDiT(nn.Module):
                 idx = torch.nonzero(m.reshape(-1) != 0, as_tuple=False).reshape(-1)
                 lens = [int(v) for v in m.sum(dim=1).tolist()]
                 off = seq_offsets(lens, y.device)
-                self._mask_cache = (key, idx, lens, off)
-            _, idx, lens, off = self._mask_cache
+                self._mask_cache = (key, idx, lens, off, mask)   # the mask is kept alive: its address cannot be recycled
+            _, idx, lens, off = self._mask_cache[:4]
             ysel = y.squeeze(1).reshape(-1, C).index_select(0, idx).reshape(1, -1, C)
             return ysel, lens, off
         mask_ = mask if mask.shape[0] == B else mask.repeat([2, 1])
@@ -562,9 +576,7 @@ class STDiT(nn.Module):
         fp = all(not getattr(m, "weight_quant", False) and not getattr(m, "act_quant", False) for m in fcs)
         key = None
         if self.cache_prompt and fp and not self.training:
-            key = (y.data_ptr(), y._version, tuple(y.shape), y.dtype,
-                   None if mask is None else (mask.data_ptr(), mask._version, tuple(mask.shape)),
-                   fcs[0].weight.data_ptr(), fcs[0].weight._version)
+            key = (y, mask, fcs[0].weight, fcs[1].weight)
             hit = self._prompt_cache.get(key)
             if hit is not None:
                 return hit
