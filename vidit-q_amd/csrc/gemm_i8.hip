@@ -616,6 +616,31 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
     const int* l_R = reinterpret_cast<const int*>(smem + PAR_OFF + 16 * BN) + 2 * BM;
     uint8_t* slab = smem + wave * SLAB;
     if (ts) ts[3] = __builtin_readcyclecounter();
+    constexpr int CPR = WTN / 8;                      // 16-byte chunks per slab row
+    constexpr int NCH = WTM * CPR;
+    constexpr int NITER = (NCH + 63) / 64;
+    const int mrow0 = m0 + wm * WTM, ncol0 = n0 + wn * WTN;
+    // residual operand of the fused adds: this lane's chunks are requested DURING the dequant phase, two per finished
+    // channel tile (whose 16 accumulator registers they inherit), so that the ~3 us of VALU work covers their HBM
+    // latency; requested one unrolled batch at a time inside the store loop they cost +8..10 us per launch
+    constexpr bool HAS_RES = (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID);
+    half8 rres[HAS_RES ? NITER : 1];
+    auto fetch_res = [&](int it) {
+        const int c = lane + it * 64;
+        const int row = c / CPR, col = (c % CPR) * 8;
+        const int m = mrow0 + row, n = ncol0 + col;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rres[it][q] = (half_t)0.f;
+        if (c < NCH && m < a.M && n < a.N) {
+            const size_t off = (size_t)m * a.ldo + n;
+            if (n + 8 <= a.N) rres[it] = *reinterpret_cast<const half8*>(a.resid + off);
+            else {
+                const half4 r4 = *reinterpret_cast<const half4*>(a.resid + off);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rres[it][q] = r4[q];
+            }
+        }
+    };
     {
         float sxm[TM];
         int nzx[TM], Rm[TM];
@@ -649,15 +674,20 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                 }
                 *reinterpret_cast<half4*>(slab + (i * 16 + frow) * ROWB + (j * 16 + 4 * fc) * 2) = o;
             }
+            if constexpr (HAS_RES) {
+                constexpr int PER = (NITER + TN - 1) / TN;
+#pragma unroll
+                for (int u = 0; u < PER; ++u)
+                    if (j * PER + u < NITER) fetch_res(j * PER + u);
+            }
         }
     }
     if (ts) ts[4] = __builtin_readcyclecounter();
     // second pass: this wave's slab, row-major 16-byte chunks (same wave wrote it: LDS ops are in order)
-    constexpr int CPR = WTN / 8;                      // 16-byte chunks per slab row
-    constexpr int NCH = WTM * CPR;
-    const int mrow0 = m0 + wm * WTM, ncol0 = n0 + wn * WTN;
-#pragma unroll 6
-    for (int c = lane; c < NCH; c += 64) {
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int c = lane + it * 64;
+        if (NCH % 64 != 0 && c >= NCH) continue;
         const int row = c / CPR, col = (c % CPR) * 8;
         const int m = mrow0 + row, n = ncol0 + col;
         if (m >= a.M || n >= a.N) continue;
@@ -665,29 +695,23 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
         const size_t off = (size_t)m * a.ldo + n;
         const bool full = n + 8 <= a.N;               // N % 4 == 0: otherwise exactly 4 valid
         if constexpr (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID) {
-            half8 rr;
-            if (full) rr = *reinterpret_cast<const half8*>(a.resid + off);
-            else {
-                const half4 r4 = *reinterpret_cast<const half4*>(a.resid + off);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { rr[e] = r4[e]; rr[4 + e] = (half_t)0.f; }
-            }
+            const half8 rr = rres[it];
             if constexpr (EPI == VQ_EPI_GATE_RESID) {
                 const float* g = a.gate + (size_t)(m / a.rows_per_gate) * a.N + n;
                 const float4v g0 = *reinterpret_cast<const float4v*>(g);
                 const float4v g1 = full ? *reinterpret_cast<const float4v*>(g + 4) : float4v{0, 0, 0, 0};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)rr[e] + (e < 4 ? g0[e] : g1[e - 4]) * (float)y[e]);
+                for (int q = 0; q < 8; ++q) y[q] = (half_t)((float)rr[q] + (q < 4 ? g0[q] : g1[q - 4]) * (float)y[q]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)rr[e] + (float)y[e]);
+                for (int q = 0; q < 8; ++q) y[q] = (half_t)((float)rr[q] + (float)y[q]);
             }
         }
         if (full) *reinterpret_cast<half8*>(a.out + off) = y;
         else {
             half4 y4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y4[e] = y[e];
+            for (int q = 0; q < 4; ++q) y4[q] = y[q];
             *reinterpret_cast<half4*>(a.out + off) = y4;
         }
     }
