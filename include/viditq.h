@@ -147,6 +147,16 @@ int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32
                int rows_per_gate, int M, int N, int K, int Kp, int w_bits, int epilogue,
                int variant, void* stream);
 
+/* Batched form of vq_gemm_i8 for ONE activation and nbatch stacked weight sets:
+ *   out[b] [M, N] fp16 = dequant(xq . wq[b]^T) + bias[b],   b = 0 .. nbatch-1
+ * wq [nbatch, N, Kp] int8, sw / zw / cs / bias [nbatch, N], out [nbatch, M, N] contiguous.  Used for the kv_linear of
+ * all transformer blocks: MultiHeadCrossAttention.kv_linear (t2v/opensora/models/layers/blocks.py:297) is applied by
+ * every block to the same prompt tokens, so one launch of nbatch x ceil(N/288) workgroups replaces nbatch launches
+ * of ceil(N/288) workgroups each.  8-bit weights, no fused epilogue. */
+int vq_gemm_i8_batched(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R, const void* wq,
+                       const float* sw, const int32_t* zw, const int32_t* cs, const float* bias, void* out,
+                       int nbatch, int M, int N, int K, int Kp, int w_bits, void* stream);
+
 /* ---- fp16 attention (fp32 online softmax) -----------------------------------
  * Replaces flash_attn_func / the softmax branch of Attention.forward
  * (opensora/models/layers/blocks.py:169-187), xformers block-diagonal

@@ -358,3 +358,23 @@ def test_gelu_rowquant_matches_gelu_then_rowquant(ops, dev, C, smooth):
     if smooth:
         ref = ref / s
     assert rel_l2(deq.cpu(), ref.cpu()) < 1e-2      # 8-bit quantization noise itself
+
+
+def test_gemm_i8_batched_equals_separate_launches(ops, dev):
+    """vq_gemm_i8_batched: one activation, stacked weight sets (the kv_linear of every block on the same prompt
+    tokens) - bit-identical to one vq_gemm_i8 launch per weight set."""
+    M, N, K, nb = 120, 2304, 1152, 5
+    x = h16(1, M, K, scale=1.0, seed=3)
+    qa = ops.rowquant(x.to(dev))
+    pws, biases, outs = [], [], []
+    for b in range(nb):
+        W = h16(N, K, scale=0.04, seed=10 + b).to(dev)
+        d, z = ops.weight_minmax(W, 8)
+        pws.append(ops.pack_weight(W, d, z, 8))
+        biases.append(h16(N, scale=0.1, seed=20 + b).float().to(dev))
+        outs.append(ops.gemm_i8(qa, pws[-1], bias=biases[-1]))
+    st = ops.stack_packed(pws, biases)
+    got = ops.gemm_i8_batched(qa, st)
+    assert got.shape == (nb, M, N)
+    for b in range(nb):
+        assert torch.equal(got[b], outs[b])

@@ -29,6 +29,7 @@ SIGNATURES = {
     "vq_fakequant_act": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "vq_pack_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vq_weight_minmax": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vq_gemm_i8_batched": (_i, [_vp] * 10 + [_i] * 6 + [_vp]),
     "vq_gemm_i8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp,
                         _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _vp, _f, _vp]),

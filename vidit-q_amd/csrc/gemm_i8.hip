@@ -57,6 +57,10 @@ struct GemmArgs {
     const float* gate;
     int ldo, rows_per_gate, M, N, K, Kp, epilogue;
     int nkt_dbg;  // > 0: run only this many k-tiles (ablation for profiling; results are then wrong)
+    // batched launch (vq_gemm_i8_batched): nbatch weight sets applied to the SAME activation; strides in elements
+    // of the respective arrays (wq bytes, per-channel arrays, out halves)
+    int nbatch;
+    long bs_w, bs_ch, bs_out;
 };
 
 // Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (bid % 8), each with its own 4 MiB
@@ -974,7 +978,21 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
     }
 
     int mt_, nt_;
-    xcd_tile(blockIdx.x, (a.M + BM - 1) / BM, (a.N + BN - 1) / BN, mt_, nt_);
+    {
+        const int MT_ = (a.M + BM - 1) / BM, NT_ = (a.N + BN - 1) / BN;
+        int vb = blockIdx.x;
+        if (a.nbatch > 1) {                            // batch-major grid: weight set = blockIdx / tiles
+            const int bt = vb / (MT_ * NT_);
+            vb -= bt * (MT_ * NT_);
+            a.wq += (size_t)bt * a.bs_w;
+            a.sw += (size_t)bt * a.bs_ch;
+            a.zw += (size_t)bt * a.bs_ch;
+            a.cs += (size_t)bt * a.bs_ch;
+            if (a.bias) a.bias += (size_t)bt * a.bs_ch;
+            a.out += (size_t)bt * a.bs_out;
+        }
+        xcd_tile(vb, MT_, NT_, mt_, nt_);
+    }
     const int m0 = mt_ * BM, n0 = nt_ * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1135,7 +1153,7 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
     }
-    hipLaunchKernelGGL(k, dim3(MT * NTl), dim3(NT), LDS, st, a);
+    hipLaunchKernelGGL(k, dim3(MT * NTl * (a.nbatch > 1 ? a.nbatch : 1)), dim3(NT), LDS, st, a);
     return vq_check_launch();
 }
 
@@ -1659,6 +1677,25 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
 #undef VQ_ABL
     }
     return VQ_EUNSUP;
+}
+
+// One activation, nbatch stacked weight sets (e.g. the kv_linear of every transformer block applied to the same
+// prompt tokens): out[b] [M, N] = dequant(xq . wq[b]^T) + bias[b].  Default kernel only, no fused epilogue.
+extern "C" int vq_gemm_i8_batched(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R, const void* wq,
+                                  const float* sw, const int32_t* zw, const int32_t* cs, const float* bias, void* out,
+                                  int nbatch, int M, int N, int K, int Kp, int w_bits, void* stream) {
+    if (!xq || !sx || !zx || !R || !wq || !sw || !zw || !cs || !out) return VQ_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return VQ_EINVAL;
+    if (Kp % 128 != 0 || Kp < K || N % 4 != 0) return VQ_ESHAPE;
+    if (w_bits <= 4 || w_bits > 8) return VQ_EUNSUP;
+    if (K > 16384) return VQ_ESHAPE;
+    GemmArgs a{xq, sx, zx, R, (const uint8_t*)wq, sw, zw, cs, bias, (half_t*)out, nullptr, nullptr,
+               N, 1, M, N, K, Kp, VQ_EPI_NONE, 0};
+    a.nbatch = nbatch;
+    a.bs_w = (long)N * Kp;
+    a.bs_ch = N;
+    a.bs_out = (long)M * N;
+    return launch_gemm_wide<256, 288, 4, 2, true>(a, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -291,6 +291,46 @@ def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: 
 
 
 # --------------------------------------------------------------------------- attention
+@dataclass
+class PackedStack:
+    """nbatch PackedWeights of identical shape stacked for vq_gemm_i8_batched (+ their fp32 biases)."""
+    wq: torch.Tensor      # [nbatch, N, Kp] int8
+    sw: torch.Tensor      # [nbatch, N]
+    zw: torch.Tensor
+    cs: torch.Tensor
+    bias: Optional[torch.Tensor]
+    nbatch: int
+    N: int
+    K: int
+    Kp: int
+    n_bits: int
+
+
+def stack_packed(pws: Sequence[PackedWeight], biases: Sequence[Optional[torch.Tensor]]) -> PackedStack:
+    p0 = pws[0]
+    assert all(p.N == p0.N and p.K == p0.K and p.Kp == p0.Kp and p.n_bits == p0.n_bits for p in pws)
+    if p0.n_bits <= 4:
+        raise VQError("stack_packed: 8-bit (int8-stored) weights only")
+    has_b = biases[0] is not None
+    return PackedStack(torch.stack([p.wq for p in pws]).contiguous(), torch.stack([p.sw for p in pws]).contiguous(),
+                       torch.stack([p.zw for p in pws]).contiguous(), torch.stack([p.cs for p in pws]).contiguous(),
+                       torch.stack([b.float() for b in biases]).contiguous() if has_b else None,
+                       len(pws), p0.N, p0.K, p0.Kp, p0.n_bits)
+
+
+def gemm_i8_batched(a: QAct, w: PackedStack, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] [M, N] fp16 for every stacked weight set b, all from the same quantized activation ``a``."""
+    if a.K != w.K or a.Kp != w.Kp:
+        raise VQError("K mismatch: activation %d/%d weight %d/%d" % (a.K, a.Kp, w.K, w.Kp))
+    M = a.rows
+    if out is None:
+        out = torch.empty((w.nbatch, M, w.N), dtype=torch.float16, device=a.xq.device)
+    check(_L().vq_gemm_i8_batched(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs),
+                                  _p(w.bias), _p(out), w.nbatch, M, w.N, a.K, a.Kp, w.n_bits, _stream()),
+          "vq_gemm_i8_batched")
+    return out
+
+
 def attn_fwd(q, k, v, o, n_seq, Lq, Lk, H, D, q_seq_stride, q_tok_stride, kv_seq_stride, kv_tok_stride,
              o_seq_stride, o_tok_stride, kv_off: Optional[torch.Tensor] = None, scale: Optional[float] = None):
     """Flash attention over strided fp16 views (pointers are the tensors' data_ptr())."""
