@@ -384,7 +384,7 @@ class STDiTBlock(nn.Module):
                 self._kv_cache.put(kkey, kv)
         return kv
 
-    def forward_fused(self, x2, y2, t0, y_lens, tpe, B, kv_ready=None):
+    def forward_fused(self, x2, y2, t0, y_lens, tpe, B, kv_ready=None, mod=None):
         """In-place update of the residual stream x2 [B*T*S, C] fp16, rows ordered (b, t, s)."""
         T, S, C = self.d_t, self.d_s, self.hidden_size
         N = T * S
@@ -397,7 +397,8 @@ class STDiTBlock(nn.Module):
             rr, alpha = layer._range_and_alpha()
             return layer.smooth_vector(rr, alpha)
 
-        mod = ops.adaln_table(self.scale_shift_table.detach(), t0.reshape(B, -1))   # [6, B, C] fp32
+        if mod is None:
+            mod = ops.adaln_table(self.scale_shift_table.detach(), t0.reshape(B, -1))   # [6, B, C] fp32
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = [mod[j] for j in range(6)]
         x3 = x2.view(B, N, C)
         st = a1.q.status
@@ -499,6 +500,7 @@ class STDiT(nn.Module):
         self._prompt_cache = _SmallCache(8)
         self.cache_prompt = False
         self._kv_stack = None
+        self._adaln_stack = None
 
     # ---- embeddings / init (stdit.py:367-442) ------------------------------------------------
     def get_spatial_pos_embed(self):
@@ -577,6 +579,17 @@ class STDiT(nn.Module):
             b._kv_cache = _SmallCache(8)
         self._prompt_cache = _SmallCache(8)
 
+    def _all_adaln(self, t0, B):
+        """mod[6 i + j] = scale_shift_table_i[j] + t0[:, j]  for every block i: one launch on the stacked tables
+        instead of one per block (t0 is the same for all blocks: stdit.py:304-306)."""
+        tabs = [b.scale_shift_table for b in self.blocks]
+        sig = tuple((t.data_ptr(), t._version) for t in tabs)
+        st = self._adaln_stack
+        if st is None or st[0] != sig:
+            st = self._adaln_stack = (sig, torch.cat([t.detach() for t in tabs], dim=0).contiguous(), tabs)
+        n = len(tabs)
+        return ops.adaln_table(st[1], t0.reshape(B, -1).repeat(1, n).contiguous())   # [6 n, B, C] fp32
+
     def _all_prompt_kv(self, y2):
         """K/V of the prompt for EVERY block in two launches: the blocks' kv_linear layers see the same input y2, so
         (without smooth quant) the same quantized activation, and their [2C, C] weights are stacked into one batched
@@ -640,9 +653,10 @@ class STDiT(nn.Module):
                 off = seq_offsets(y_lens, x.device)
             t0c = t0.contiguous()
             kvs = self._all_prompt_kv(y2)              # one quantizer + ONE batched GEMM for all blocks (or None)
+            mods = self._all_adaln(t0c, B)             # every block's AdaLN table in one launch
             for i, block in enumerate(self.blocks):
                 block.forward_fused(x2, y2, t0c, off, self.pos_embed_temporal if i == 0 else None, B,
-                                    kv_ready=None if kvs is None else kvs[i])
+                                    kv_ready=None if kvs is None else kvs[i], mod=mods[6 * i:6 * i + 6])
             x = x2.reshape(B, self.num_patches, C)
         else:
             for i, block in enumerate(self.blocks):
