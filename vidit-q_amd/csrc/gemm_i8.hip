@@ -524,10 +524,11 @@ struct ColParams {
     int nzw, cs;
 };
 template <int BN>
-__device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int n0) {
+__device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int n0, int tid_in = -1) {
     ColParams c{0.f, 0.f, 0, 0};
-    const int gn = n0 + (int)threadIdx.x;
-    if ((int)threadIdx.x < BN && gn < a.N) {
+    const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
+    const int gn = n0 + tx;
+    if (tx < BN && gn < a.N) {
         c.sw = a.sw[gn];
         c.nzw = -a.zw[gn];
         c.cs = a.cs[gn];
@@ -536,15 +537,16 @@ __device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int
     return c;
 }
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
-__device__ __forceinline__ void ring_park_col_params(const ColParams& c, uint8_t* smem) {
+__device__ __forceinline__ void ring_park_col_params(const ColParams& c, uint8_t* smem, int tid_in = -1) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     static_assert(BN <= NT, "one channel per thread");
     constexpr int PAR_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD);
-    if ((int)threadIdx.x < BN) {
-        reinterpret_cast<float*>(smem + PAR_OFF)[threadIdx.x] = c.sw;
-        reinterpret_cast<int*>(smem + PAR_OFF)[BN + threadIdx.x] = c.nzw;
-        reinterpret_cast<int*>(smem + PAR_OFF)[2 * BN + threadIdx.x] = c.cs;
-        reinterpret_cast<float*>(smem + PAR_OFF)[3 * BN + threadIdx.x] = c.b;
+    const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
+    if (tx < BN) {
+        reinterpret_cast<float*>(smem + PAR_OFF)[tx] = c.sw;
+        reinterpret_cast<int*>(smem + PAR_OFF)[BN + tx] = c.nzw;
+        reinterpret_cast<int*>(smem + PAR_OFF)[2 * BN + tx] = c.cs;
+        reinterpret_cast<float*>(smem + PAR_OFF)[3 * BN + tx] = c.b;
     }
 }
 
@@ -555,10 +557,11 @@ struct RowParams {
     int nzx, R;
 };
 template <int BM>
-__device__ __forceinline__ RowParams ring_load_row_params(const GemmArgs& a, int m0) {
+__device__ __forceinline__ RowParams ring_load_row_params(const GemmArgs& a, int m0, int tid_in = -1) {
     RowParams r{0.f, 0, 0};
-    if ((int)threadIdx.x < BM) {
-        const int m = m0 + (int)threadIdx.x;
+    const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
+    if (tx < BM) {
+        const int m = m0 + tx;
         const int mc = m < a.M ? m : a.M - 1;
         r.sx = a.sx[mc];
         r.nzx = -a.zx[mc];
@@ -567,26 +570,27 @@ __device__ __forceinline__ RowParams ring_load_row_params(const GemmArgs& a, int
     return r;
 }
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
-__device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t* smem) {
+__device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t* smem, int tid_in = -1) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     static_assert(BM <= NT, "one token row per thread");
     constexpr int ROW_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD) + 16 * BN;
     static_assert(ROW_OFF + 12 * BM <= 163840, "LDS budget");
-    if ((int)threadIdx.x < BM) {
-        reinterpret_cast<float*>(smem + ROW_OFF)[threadIdx.x] = r.sx;
-        reinterpret_cast<int*>(smem + ROW_OFF)[BM + threadIdx.x] = r.nzx;
-        reinterpret_cast<int*>(smem + ROW_OFF)[2 * BM + threadIdx.x] = r.R;
+    const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
+    if (tx < BM) {
+        reinterpret_cast<float*>(smem + ROW_OFF)[tx] = r.sx;
+        reinterpret_cast<int*>(smem + ROW_OFF)[BM + tx] = r.nzx;
+        reinterpret_cast<int*>(smem + ROW_OFF)[2 * BM + tx] = r.R;
     }
 }
 
 // Stage both parameter blocks (called once all fragment reads of the main loop are issued; the blocks lie
 // past the end of every ring, so no barrier is needed before writing them, only before reading them).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
-__device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* smem, int m0, int n0) {
-    const ColParams colp = ring_load_col_params<BN>(a, n0);
-    const RowParams rowp = ring_load_row_params<BM>(a, m0);
-    ring_park_col_params<BM, BN, WAVES_M, WAVES_N, PAD>(colp, smem);
-    ring_park_row_params<BM, BN, WAVES_M, WAVES_N, PAD>(rowp, smem);
+__device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* smem, int m0, int n0, int tid_in = -1) {
+    const ColParams colp = ring_load_col_params<BN>(a, n0, tid_in);
+    const RowParams rowp = ring_load_row_params<BM>(a, m0, tid_in);
+    ring_park_col_params<BM, BN, WAVES_M, WAVES_N, PAD>(colp, smem, tid_in);
+    ring_park_row_params<BM, BN, WAVES_M, WAVES_N, PAD>(rowp, smem, tid_in);
 }
 
 // Shared epilogue of the LDS-DMA ring kernels (called after a workgroup barrier; uses all of smem; the
@@ -594,11 +598,13 @@ __device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* sm
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16>
 __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                                               int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
-                                              long long* ts = nullptr) {
+                                              long long* ts = nullptr, int tid_in = -1) {
+    // tid_in: the persistent kernel passes an opaque copy of threadIdx.x per tile so that the address arithmetic
+    // below is not hoisted out of its tile loop (and kept in registers through the main loop)
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int frow = lane & 15, fc = lane >> 4;
@@ -1168,6 +1174,292 @@ static int launch_gemm_wide(const GemmArgs& a, hipStream_t st) {
     }
 }
 
+// Epilogue of the persistent kernel (EPI NONE / GELU): same arithmetic and store pattern as ring_epilogue, but the
+// wave tile is dequantised in two passes of 32 token rows, so the eight slabs take 76 KiB instead of 152 and can
+// live in the ring's stage-1 region while stage 0 already receives the next tile.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__device__ __forceinline__ void ring_epilogue_halves(const GemmArgs& a, uint8_t* smem, int slab_base,
+                                                     int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
+                                                     int tid) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    static_assert(TM % 2 == 0, "two passes");
+    constexpr int ROWB = WTN * 2 + 16;
+    constexpr int HROWS = WTM / 2;
+    constexpr int SLABH = HROWS * ROWB;
+    constexpr int PAR_OFF = NW * WTM * ROWB;          // where ring_stage_params parks the parameter blocks
+    static_assert(NW * SLABH <= PAR_OFF, "slabs below the parameter block");
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int frow = lane & 15, fc = lane >> 4;
+    const float* l_sw = reinterpret_cast<const float*>(smem + PAR_OFF);
+    const int* l_nzw = reinterpret_cast<const int*>(smem + PAR_OFF) + BN;
+    const int* l_cs = reinterpret_cast<const int*>(smem + PAR_OFF) + 2 * BN;
+    const float* l_b = reinterpret_cast<const float*>(smem + PAR_OFF) + 3 * BN;
+    const float* l_sx = reinterpret_cast<const float*>(smem + PAR_OFF + 16 * BN);
+    const int* l_nzx = reinterpret_cast<const int*>(smem + PAR_OFF + 16 * BN) + BM;
+    const int* l_R = reinterpret_cast<const int*>(smem + PAR_OFF + 16 * BN) + 2 * BM;
+    uint8_t* slab = smem + slab_base + wave * SLABH;
+    constexpr int CPR = WTN / 8;
+    constexpr int NCH = HROWS * CPR;
+    constexpr int NITER = (NCH + 63) / 64;
+    const int ncol0 = n0 + wn * WTN;
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+        float sxm[TM / 2];
+        int nzx[TM / 2], Rm[TM / 2];
+#pragma unroll
+        for (int ii = 0; ii < TM / 2; ++ii) {
+            const int rl = wm * WTM + (hp * (TM / 2) + ii) * 16 + frow;
+            sxm[ii] = l_sx[rl];
+            nzx[ii] = l_nzx[rl];
+            Rm[ii] = l_R[rl];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * WTN + j * 16 + 4 * fc;
+            const float4v fsw_ = *reinterpret_cast<const float4v*>(l_sw + nl);
+            const int4v nzw = *reinterpret_cast<const int4v*>(l_nzw + nl);
+            const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
+            const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
+#pragma unroll
+            for (int ii = 0; ii < TM / 2; ++ii) {
+                const int i = hp * (TM / 2) + ii;
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int t1, tt;                        // acc - zw*R - zx*cs, exact in int32 (see ring_epilogue)
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(nzw[e]), "v"(Rm[ii]), "v"(acc[j][i][e]));
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(tt) : "v"(nzx[ii]), "v"(ics[e]), "v"(t1));
+                    float y = (sxm[ii] * fsw_[e]) * (float)tt + fb[e];
+                    if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
+                    o[e] = (half_t)y;
+                }
+                *reinterpret_cast<half4*>(slab + (ii * 16 + frow) * ROWB + (j * 16 + 4 * fc) * 2) = o;
+            }
+        }
+        const int mrow0 = m0 + wm * WTM + hp * HROWS;
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            const int c = lane + it * 64;
+            if (NCH % 64 != 0 && c >= NCH) continue;
+            const int row = c / CPR, col = (c % CPR) * 8;
+            const int m = mrow0 + row, n = ncol0 + col;
+            if (m >= a.M || n >= a.N) continue;
+            const half8 y = *reinterpret_cast<const half8*>(slab + row * ROWB + col * 2);
+            const size_t off = (size_t)m * a.ldo + n;
+            if (n + 8 <= a.N) *reinterpret_cast<half8*>(a.out + off) = y;
+            else {
+                half4 y4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y4[q] = y[q];
+                *reinterpret_cast<half4*>(a.out + off) = y4;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Persistent full-line ring kernel (variant 14; EPI NONE / GELU, int8 weights).  Same tile, stages, fragment
+// rings and epilogue as gemm_i8_wide_kernel, but ONE workgroup per CU walks tiles b, b + G, b + 2G, ... (the
+// order the dispatcher would have given them, so the XCD/L2 behaviour is that of variant 11), and the cold
+// start of every tile after the first is taken off the critical path (tools/gemm_stamps.py: 4.3 k of a
+// tile's 43 k cycles is the wait for the first DMA batch):
+//   * the epilogue runs in two passes of 32 token rows per wave, so its slabs (76 KiB) fit in the stage-1
+//     region and the NEXT tile's stage 0 is requested by LDS-DMA right after the barrier that ends the main
+//     loop: it lands during the dequant phase (a register prefetch instead spilled: 256 VGPRs are all taken);
+//   * once every wave has read its slabs back (lgkmcnt + s_barrier: no vmcnt(0), the stores keep draining),
+//     stage 1 of the next tile is requested, and a counted vmcnt + barrier hands stage 0 to the main loop.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_persist_kernel(GemmArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int XP = BM / 8, WP = BN * 128 / 1024;
+    constexpr int STAGE = BM * 128 + BN * 128;
+    constexpr int PIECES = XP + WP;
+    constexpr int PPW = (PIECES + NW - 1) / NW;
+    constexpr int PLAST = PIECES - (PPW - 1) * NW;
+    constexpr int BARJ = TN - 2;
+    constexpr int DMA_B = TN >= 6 ? 3 : 0;
+    static_assert(TM == 4 && TN >= 3 && TN % 3 == 0, "fragment rings below");
+    static_assert(EPI == VQ_EPI_NONE || EPI == VQ_EPI_GELU, "no residual operand: the epilogue issues stores only");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const bool full_wave = (PIECES % NW == 0) || wave < PLAST;
+    const bool late = wave >= NW / 2;
+    const int MT_ = (a.M + BM - 1) / BM, NT_ = (a.N + BN - 1) / BN;
+    const int ntiles = MT_ * NT_;
+    const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
+    const int frow = lane & 15, fc = lane >> 4;
+    const int xf0 = (wm * WTM + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int wf0 = BM * 128 + (wn * WTN + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int xf1 = xf0 ^ 64, wf1 = wf0 ^ 64;
+    auto ldx = [&](int stage, int h, int i) {
+        return *reinterpret_cast<const int4v*>(smem + stage * STAGE + (h ? xf1 : xf0) + i * 16 * 128);
+    };
+    auto ldw = [&](int stage, int h, int j) {
+        return *reinterpret_cast<const int4v*>(smem + stage * STAGE + (h ? wf1 : wf0) + j * 16 * 128);
+    };
+    // byte offsets of this lane's DMA pieces for tile (m0, n0): X pieces from xq, W pieces from wq
+    // (ln = an opaque per-tile copy of the lane id: otherwise the row / swizzle terms are hoisted out of the tile
+    //  loop and spilled around the main loop)
+    auto piece_offsets = [&](int m0, int n0, int ln, uint32_t (&so)[PPW]) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + i * NW;
+            const int r = (p < XP ? p : p - XP) * 8 + (ln >> 3);
+            const int c = (ln & 7) ^ ((r >> 1) & 7);
+            int g = (p < XP ? m0 : n0) + r;
+            const int lim = p < XP ? a.M : a.N;
+            g = g < lim ? g : lim - 1;
+            so[i] = (uint32_t)g * (uint32_t)a.Kp + c * 16;
+        }
+    };
+    const int nkt = a.Kp / 128;                       // host guarantees nkt >= 2
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int mt_, nt_;
+        xcd_tile(tile, MT_, NT_, mt_, nt_);
+        const int m0 = mt_ * BM, n0 = nt_ * BN;
+        uint32_t soff[PPW];
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        piece_offsets(m0, n0, lane_t, soff);
+        auto issue = [&](int stage, int kt) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int p = wave + i * NW;
+                if (PIECES % NW == 0 || p < PIECES) {
+                    const uint8_t* g = (p < XP ? xbase : a.wq) + soff[i] + kt * 128;
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                                     (void __attribute__((address_space(3)))*)(smem + stage * STAGE + p * 1024),
+                                                     16, 0, 0);
+                }
+            }
+        };
+        if (tile == (int)blockIdx.x) {                // first tile of this workgroup: cold prologue
+            issue(0, 0);
+            issue(1, 1);
+            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }                                             // else: stage 0 written + barrier passed at the end of the previous tile
+
+        int4v acc[TN][TM];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
+        int4v xa[TM], xb[TM];
+        int4v w[3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[i] = ldx(0, 0, i);
+        w[0] = ldw(0, 0, 0);
+        w[1] = ldw(0, 0, 1);
+
+#define VQ_PERS_STEP(X, XN, H)                                                                             \
+    {                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+            if (H == 1 && j == BARJ && more) {                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+                __builtin_amdgcn_s_barrier();                                                              \
+                if (!late && kt + 2 < nkt) issue(cur, kt + 2);                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (H == 0 && j == DMA_B && late && kt >= 1 && more) {                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                issue(nxt, kt + 1);                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (j + 2 < TN) w[(j + 2) % 3] = ldw(cur, H, j + 2);                                           \
+            else if (H == 0) w[(j + 2) % 3] = ldw(cur, 1, j + 2 - TN);                                     \
+            else if (more) w[(j + 2) % 3] = ldw(nxt, 0, j + 2 - TN);                                       \
+            if (H == 0 || more) {                                                                          \
+                if (j == TN - 2) { XN[0] = ldx(H == 0 ? cur : nxt, 1 - H, 0); XN[1] = ldx(H == 0 ? cur : nxt, 1 - H, 1); } \
+                if (j == TN - 1) { XN[2] = ldx(H == 0 ? cur : nxt, 1 - H, 2); XN[3] = ldx(H == 0 ? cur : nxt, 1 - H, 3); } \
+            }                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+                acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[j % 3], X[i], acc[j][i], 0, 0, 0);     \
+            if (j >= TN - 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                            \
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
+        }                                                                                                  \
+    }
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1, nxt = cur ^ 1;
+            const bool more = kt + 1 < nkt;
+            VQ_PERS_STEP(xa, xb, 0)
+            VQ_PERS_STEP(xb, xa, 1)
+        }
+#undef VQ_PERS_STEP
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));               // opaque per tile: keeps the epilogue's address math inside the loop
+        ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0, tid_e);
+        const int ntile = tile + (int)gridDim.x;
+        const bool has_next = ntile < ntiles;         // workgroup-uniform
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // parameter block visible, every fragment read of the ring done
+        if (has_next) {                               // next tile: stage 0 lands during the dequant phase
+            int nm, nn;
+            xcd_tile(ntile, MT_, NT_, nm, nn);
+            piece_offsets(nm * BM, nn * BN, tid_e & 63, soff);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ring_epilogue_halves<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, STAGE, acc, m0, n0, tid_e);
+        if (has_next) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // all slabs read back: the stage-1 region is free (stores drain on their own)
+            issue(1, 1);
+            // everything but the stage-1 batch just issued: stage 0 of the next tile (and this tile's stores, which
+            // were issued ~1 k cycles of DMA issue ago) - a count, not vmcnt(0), so stage 1 keeps flying
+            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
+static int vq_num_cus() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+static int launch_gemm_persist_e(const GemmArgs& a, hipStream_t st) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * 128);
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4 + 12 * BM;
+    constexpr size_t LDS = RING > EPIL ? RING : EPIL;
+    static_assert(LDS <= 163840, "LDS budget of one CU");
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int grid = tiles < vq_num_cus() ? tiles : vq_num_cus();
+    auto k = gemm_i8_persist_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS, st, a);
+    return vq_check_launch();
+}
+
 // ---------------------------------------------------------------------------
 // Ping-pong kernel (variant 13).  tools/mfma_rate.py: a fragment read placed BETWEEN MFMAs costs the
 // in-order wave ~14 matrix-pipe cycles (36 MFMA + 13 ds_read_b128 interleaved: 0.71 us per k-step),
@@ -1630,6 +1922,15 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         case 11:  // full-line double buffer: 128 bytes of k per row and stage, staggered DMA issue
             if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, true, true>(a, st);
             return launch_gemm_wide<256, 288, 4, 2, true>(a, st);
+        case 14: {  // persistent full-line ring with next-tile prefetch where a launch has more tiles than CUs
+            const int tiles = ((a.M + 255) / 256) * ((a.N + 287) / 288);
+            if (w_bits > 4 && a.nbatch <= 1 && a.Kp >= 256 && tiles > vq_num_cus()) {
+                if (a.epilogue == VQ_EPI_NONE) return launch_gemm_persist_e<256, 288, 4, 2, VQ_EPI_NONE>(a, st);
+                if (a.epilogue == VQ_EPI_GELU) return launch_gemm_persist_e<256, 288, 4, 2, VQ_EPI_GELU>(a, st);
+            }
+            if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, true, true>(a, st);
+            return launch_gemm_wide<256, 288, 4, 2, true>(a, st);
+        }
         case 13:  // ping-pong: SIMD partners alternate MFMA-only and load-only segments
             if (w_bits <= 4) return launch_gemm_pp<256, 288, 4, 2, true>(a, st);
             return launch_gemm_pp<256, 288, 4, 2>(a, st);
