@@ -339,6 +339,34 @@ def test_attn_temporal(ops, dev, B, T, S, H, D):
     assert rel_l2(o.cpu().float(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("T,S,H,D", [(16, 64, 16, 72), (16, 37, 16, 72), (4, 8, 4, 16), (5, 9, 4, 16), (16, 16, 8, 64), (3, 5, 2, 32)])
+def test_attn_temporal_rowquant_equals_two_kernels(ops, dev, T, S, H, D):
+    """The fused kernel = temporal attention, then the per-token quantizer on ITS fp16 output: codes, scales, zero
+    points and row sums bit-identical to vq_rowquant applied to the fp16 copy it can emit; that copy agrees with the
+    stand-alone attention kernel to one fp16 ulp in a handful of elements (both are within the 1e-3 attention tolerance
+    of the oracle, checked in test_attn_temporal)."""
+    Cc = H * D
+    qkv = h16(T * S, 3 * Cc, seed=T * 31 + S).to(dev)
+    qkv[(T - 1) * S + 1, 2 * Cc:] = 0                   # one value row zeroed (still a normal output row)
+    o_ref = torch.empty((T * S, Cc), dtype=torch.float16, device=dev)
+    ops.attn_temporal(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], o_ref, 1, T, S, H, D, 3 * Cc, Cc)
+    st1 = torch.zeros(1, dtype=torch.int32, device=dev)
+    o = torch.zeros_like(o_ref)
+    got = ops.attn_temporal_rowquant(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], 1, T, S, H, D, 3 * Cc, status=st1, o=o)
+    st0 = torch.zeros(1, dtype=torch.int32, device=dev)
+    ref = ops.rowquant(o.view(1, T * S, Cc), status=st0)
+    assert got.K == ref.K and got.xq.shape == ref.xq.shape
+    assert torch.equal(got.sx, ref.sx) and torch.equal(got.zx, ref.zx) and torch.equal(got.R, ref.R)
+    assert torch.equal(got.xq, ref.xq)
+    assert int(st0.item()) == int(st1.item())
+    diff = (o.float() - o_ref.float()).abs()
+    assert float((diff > 0).float().mean()) < 2e-3
+    assert bool((diff <= 2.0 ** -10 * o_ref.float().abs().clamp(min=2.0 ** -14)).all())     # one fp16 ulp
+    # without the optional fp16 copy: same codes
+    got2 = ops.attn_temporal_rowquant(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], 1, T, S, H, D, 3 * Cc)
+    assert torch.equal(got2.xq, got.xq) and torch.equal(got2.R, got.R) and torch.equal(got2.sx, got.sx)
+
+
 # ----------------------------------------------------------------------------- small fused helpers
 def test_adaln_table_and_cfg_ddim(ops, dev):
     B, J, C = 2, 6, 64

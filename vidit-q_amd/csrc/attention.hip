@@ -392,6 +392,232 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(TempArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// attn_temporal_quant_kernel: temporal attention + the per-token quantizer of the Linear that consumes it
+// (attn_temp.proj's DynamicActQuantizer, stdit.py:116 -> stdit_quant_layer.py:161-166) in one pass.
+// A token's quantizer needs its whole row (all heads), so one workgroup = ONE spatial position x ALL heads
+// (one wave per head, H <= 16), the T <= 16 rows of q | k | v staged once through LDS.  Each wave computes its
+// head with 16x16x16 MFMAs (S^T = K Q^T leaves the matrix core in the layout P^T needs as the B operand of
+// O^T = V^T P^T), rounds the output to fp16 as the unfused path stores it, and the row min / max / code sum are
+// combined over the waves through LDS.  The fp16 attention output (37.7 MB per block-sample) never goes to HBM and the separate
+// quantizer pass (read 37.7 MB, write 18.9 MB) disappears; codes leave through LDS as whole 16-byte chunks.
+// ---------------------------------------------------------------------------
+struct TempQArgs {
+    const half_t* q;
+    const half_t* k;
+    const half_t* v;
+    int8_t* xq;
+    float* sx;
+    int32_t* zx;
+    int32_t* R;
+    int32_t* status;
+    half_t* o;                                     // nullable: also store the fp16 attention output [B*T*S, H*D]
+    long ld_in;
+    int B, T, S, H, Kp;
+    float c;
+};
+
+template <int D>
+__global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) {
+    constexpr int KS = (D + 15) / 16;              // 16-dim k-steps of QK^T = 16-dim row tiles of O^T
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = head
+    const int tq = lane & 15, g4 = lane >> 4;      // MFMA 16x16x16: lane = (row or column tq, k / row group g4)
+    const int H = a.H, C = H * D, nthr = 64 * H;
+    const int RS = C * 2 + 16;                     // LDS row stride (odd number of 16-byte slots)
+    const int TILE = 16 * RS;
+    const int RCH = C / 8;                         // 16-byte chunks per tensor row
+    const int CROW = C + 16;                       // code row stride in LDS (rows land 4 banks apart)
+    uint8_t* codes = smem + 3 * TILE;
+    float* ex_min = reinterpret_cast<float*>(codes + 16 * CROW);
+    float* ex_max = ex_min + 256;
+    int* ex_sum = reinterpret_cast<int*>(ex_max + 256);
+    const int npos = a.S * a.B;
+
+    // One workgroup walks positions p, p + G, ...: while position p is computed from LDS, the q | k | v rows of the
+    // next one are in flight into registers (a one-position-per-workgroup version ran load -> compute -> store in
+    // lockstep on every CU: 2.8 TB/s).
+    constexpr int NITMAX = 7;                      // 3 * 16 * 144 chunks / 1024 threads (H = 16, D = 72)
+    const int nchk = 3 * 16 * RCH;
+    int4v vals[NITMAX];
+    // (tx: an opaque per-position copy of the thread id, so that the chunk -> address arithmetic is recomputed per
+    //  position instead of being hoisted out of the loop and kept in registers)
+    auto load_qkv = [&](int pos, int tx) {
+        const int s = pos % a.S, b = pos / a.S;
+#pragma unroll
+        for (int i = 0; i < NITMAX; ++i) {
+            const int c = tx + i * nthr;
+            const int ten = c / (16 * RCH), rem = c - ten * (16 * RCH);
+            const int t = rem / RCH, ch = rem - t * RCH;
+            vals[i] = int4v{0, 0, 0, 0};
+            if (c < nchk && t < a.T) {
+                const half_t* base = ten == 0 ? a.q : (ten == 1 ? a.k : a.v);
+                const long grow = ((long)b * a.T + t) * a.S + s;
+                vals[i] = *reinterpret_cast<const int4v*>(base + grow * a.ld_in + ch * 8);
+            }
+        }
+    };
+    auto store_qkv = [&](int tx) {
+#pragma unroll
+        for (int i = 0; i < NITMAX; ++i) {
+            const int c = tx + i * nthr;
+            const int ten = c / (16 * RCH), rem = c - ten * (16 * RCH);
+            const int t = rem / RCH, ch = rem - t * RCH;
+            if (c < nchk) *reinterpret_cast<int4v*>(smem + ten * TILE + t * RS + ch * 16) = vals[i];
+        }
+    };
+    const uint8_t* qs = smem + wave * D * 2;
+    const uint8_t* ksm = qs + TILE;
+    const uint8_t* vs = qs + 2 * TILE;
+
+    int pos = blockIdx.x;
+    if (pos >= npos) return;
+    load_qkv(pos, tid);
+    store_qkv(tid);
+    __syncthreads();
+    if (pos + (int)gridDim.x < npos) load_qkv(pos + (int)gridDim.x, tid);
+    for (; pos < npos; pos += gridDim.x) {
+        const int s = pos % a.S, b = pos / a.S;
+        const int npos_next = pos + (int)gridDim.x;
+        const bool has_next = npos_next < npos;    // workgroup-uniform; its rows are already in flight
+        int tx = tid;
+        asm volatile("" : "+v"(tx));
+
+        // ---- S^T[key 4*g4 + r][query tq] = K Q^T, 16 x 16 per head: lane reads 4 dims of key row tq and of query row tq
+        float4v sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + 4 * g4;
+            half4 kf = *reinterpret_cast<const half4*>(ksm + tq * RS + (d0 < D ? d0 : 0) * 2);
+            half4 qf = *reinterpret_cast<const half4*>(qs + tq * RS + (d0 < D ? d0 : 0) * 2);
+            if (d0 >= D) {
+                kf = half4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                qf = kf;
+            }
+            sc = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf, sc, 0, 0, 0);
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (4 * g4 + r >= a.T) sc[r] = -INFINITY;
+            mloc = fmaxf(mloc, sc[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_use = (mloc == -INFINITY) ? 0.f : mloc;
+        float psum = 0.f;
+        half4 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f((sc[r] - m_use) * a.c);
+            psum += p;
+            pf[r] = (half_t)p;
+        }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        const float inv_p = psum > 0.f ? __fdiv_rn(1.0f, psum) : 0.f;
+
+        // ---- O^T[dim 16*dt + 4*g4 + r][query tq] = V^T P^T: P^T is the accumulator layout of S^T already
+        float4v oacc[KS];
+        float vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+        for (int dt = 0; dt < KS; ++dt) {
+            const int d = dt * 16 + tq;
+            half4 vf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                vf[r] = d < D ? *reinterpret_cast<const half_t*>(vs + (4 * g4 + r) * RS + d * 2) : (half_t)0.f;
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            // this lane: token tq, dims 16*dt + 4*g4 + r, rounded to fp16 like the stored tensor
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y = (float)(half_t)(oacc[dt][r] * inv_p);
+                oacc[dt][r] = y;
+                if (dt * 16 + 4 * g4 < D) {
+                    vmin = fminf(vmin, y);
+                    vmax = fmaxf(vmax, y);
+                }
+            }
+        }
+        if (a.o && tq < a.T) {                     // optional fp16 copy (tests, callers that need both)
+            half_t* orow = a.o + (((long)b * a.T + tq) * a.S + s) * C + wave * D;
+#pragma unroll
+            for (int dt = 0; dt < KS; ++dt) {
+                const int d0 = dt * 16 + 4 * g4;
+                if (d0 < D) {
+                    half4 ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)oacc[dt][r];
+                    *reinterpret_cast<half4*>(orow + d0) = ov;
+                }
+            }
+        }
+        vmin = fminf(vmin, __shfl_xor(vmin, 16));
+        vmin = fminf(vmin, __shfl_xor(vmin, 32));
+        vmax = fmaxf(vmax, __shfl_xor(vmax, 16));
+        vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+        if (lane < 16) {
+            ex_min[wave * 16 + tq] = vmin;
+            ex_max[wave * 16 + tq] = vmax;
+        }
+        __syncthreads();                           // row statistics visible; every wave is done with the q | k | v tiles
+        if (has_next) {
+            store_qkv(tx);                         // next position's rows (visible after the barrier below) ...
+            if (npos_next + (int)gridDim.x < npos) load_qkv(npos_next + (int)gridDim.x, tx);   // ... and the one after it
+        }
+        vmin = INFINITY;
+        vmax = -INFINITY;
+        for (int w = 0; w < H; ++w) {
+            vmin = fminf(vmin, ex_min[w * 16 + tq]);
+            vmax = fmaxf(vmax, ex_max[w * 16 + tq]);
+        }
+        float delta, zp;
+        bool small;
+        vq_minmax_to_params(vmin, vmax, 255.0f, delta, zp, small);
+        if (small && tid < 16 && tq < a.T && a.status) atomicOr(a.status, VQ_ST_EPSFILL);
+        const float inv = __fdiv_rn(1.0f, delta);
+        const int izx = (int)zp - 128;
+        uint32_t csum = 0;
+#pragma unroll
+        for (int dt = 0; dt < KS; ++dt) {
+            const int d0 = dt * 16 + 4 * g4;
+            if (d0 < D) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rq_round_div(oacc[dt][r], inv, delta) + zp, r, pk);
+                csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
+                *reinterpret_cast<uint32_t*>(codes + tq * CROW + wave * D + d0) = pk ^ 0x80808080u;
+            }
+        }
+        int cs = (int)csum;
+        cs += __shfl_xor(cs, 16);
+        cs += __shfl_xor(cs, 32);
+        if (lane < 16) ex_sum[wave * 16 + tq] = cs;
+        __syncthreads();
+        // ---- codes out as whole 16-byte chunks (pad columns [C, Kp) zeroed like the row quantizers do); the next
+        //      iteration touches codes / ex_sum only after its own first barrier, which every thread reaches after this
+        const int kch = a.Kp / 16, cch = C / 16;
+        for (int c = tid; c < 16 * kch; c += nthr) {
+            const int t = c / kch, ch = c - t * kch;
+            if (t < a.T) {
+                const long grow = ((long)b * a.T + t) * a.S + s;
+                const int4v val = ch < cch ? *reinterpret_cast<const int4v*>(codes + t * CROW + ch * 16) : int4v{0, 0, 0, 0};
+                *reinterpret_cast<int4v*>(a.xq + grow * a.Kp + ch * 16) = val;
+            }
+        }
+        if (tid < 16 && tq < a.T) {
+            int rs = 0;
+            for (int w = 0; w < H; ++w) rs += ex_sum[w * 16 + tq];
+            const long grow = ((long)b * a.T + tq) * a.S + s;
+            a.sx[grow] = delta;
+            a.zx[grow] = izx;
+            a.R[grow] = rs - 128 * C - C * izx;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // attn_fwd8_kernel: second generation of the flash kernel above for long query sequences.
 //   * 8 waves (256 queries) share one K/V tile: half the staging work and LDS traffic per query;
 //   * V is staged DIM-major: Vt[d][32 key pairs] dwords, pair order permuted so that the four dwords an
@@ -812,6 +1038,51 @@ extern "C" int vq_attn_temporal(const void* q, const void* k, const void* v, voi
         case 64: return launch_temporal<64>(a, st);
         case 32: return launch_temporal<32>(a, st);
         case 16: return launch_temporal<16>(a, st);
+        default: return VQ_ESHAPE;
+    }
+}
+
+template <int D>
+static int launch_temporal_quant(const TempQArgs& a, hipStream_t st) {
+    const int C = a.H * D;
+    const int LDS = 3 * 16 * (C * 2 + 16) + 16 * (C + 16) + 3 * 1024;
+    auto k = attn_temporal_quant_kernel<D>;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              3 * 16 * (16 * 72 * 2 + 16) + 16 * (16 * 72 + 16) + 3 * 1024);
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    // persistent: LDS (133 KB at H*D = 1152) admits one workgroup per CU; small problems get one position each
+    const int npos = a.S * a.B;
+    static int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    const int per_cu = LDS > 80 * 1024 ? 1 : (LDS > 52 * 1024 ? 2 : 3);
+    const int grid = npos < ncu * per_cu ? npos : ncu * per_cu;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * a.H), LDS, st, a);
+    return vq_check_launch();
+}
+
+extern "C" int vq_attn_temporal_rowquant(const void* q, const void* k, const void* v, int8_t* xq, float* sx, int32_t* zx,
+                                         int32_t* R, int32_t* status, void* o, int B, int T, int S, int H, int D,
+                                         long ld_in, int Kp, float scale, void* stream) {
+    if (!q || !k || !v || !xq || !sx || !zx || !R) return VQ_EINVAL;
+    if (B <= 0 || T <= 0 || S <= 0 || H <= 0) return VQ_EINVAL;
+    const int C = H * D;
+    if (T > 16 || H > 16 || ld_in % 8 != 0 || B > 65535 || C % 16 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
+    if (3 * 16 * (C / 8) > 7 * 64 * H) return VQ_ESHAPE;          // staging registers of the kernel
+    TempQArgs a{(const half_t*)q, (const half_t*)k, (const half_t*)v, xq, sx, zx, R, status, (half_t*)o, ld_in, B, T, S, H, Kp,
+                scale * ATT_LOG2E};
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 72: return launch_temporal_quant<72>(a, st);
+        case 64: return launch_temporal_quant<64>(a, st);
+        case 32: return launch_temporal_quant<32>(a, st);
+        case 16: return launch_temporal_quant<16>(a, st);
         default: return VQ_ESHAPE;
     }
 }

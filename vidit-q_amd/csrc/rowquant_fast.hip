@@ -26,12 +26,6 @@ __device__ __forceinline__ float rq_gelu_tanh(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
 }
 
-__device__ __forceinline__ float rq_round_div(float x, float inv, float delta) {
-    const float t = x * inv;
-    float r = rintf(t);
-    if (fabsf(t - r) > 0.4999f) r = rintf(__fdiv_rn(x, delta));   // within 1e-4 of a tie: exact division
-    return r;
-}
 
 // quantize 8 values -> two packed dwords of (code - cx); returns sum of raw codes
 template <bool SAT8>

@@ -73,6 +73,16 @@ __device__ __forceinline__ float vq_code(float x, float delta, float zp, float q
     return fminf(fmaxf(q, 0.0f), qmax);
 }
 
+// round(x / delta) as the correctly rounded division would give it, at the cost of a multiply: the product with the
+// reciprocal differs from the exact quotient by < 1e-4 here, so only values that close to a rounding tie take the
+// division (shared by the row quantizers and the attention kernel with the fused quantizer)
+__device__ __forceinline__ float rq_round_div(float x, float inv, float delta) {
+    const float t = x * inv;
+    float r = rintf(t);
+    if (fabsf(t - r) > 0.4999f) r = rintf(__fdiv_rn(x, delta));
+    return r;
+}
+
 __device__ __forceinline__ void vq_minmax_to_params(float xmin, float xmax, float qmax, float& delta, float& zp,
                                                     bool& small) {
     xmin = fminf(xmin, 0.0f);  // x_min[x_min>0] = 0   (base_quantizer.py:192)

@@ -356,6 +356,33 @@ def attn_temporal(q, k, v, o, B, T, S, H, D, ld_in, ld_out, scale: Optional[floa
     return o
 
 
+def attn_temporal_rowquant(q, k, v, B, T, S, H, D, ld_in, scale: Optional[float] = None,
+                           status: Optional[torch.Tensor] = None, o: Optional[torch.Tensor] = None) -> QAct:
+    """Temporal attention + the consuming Linear's per-token 8-bit dynamic quantizer in one kernel (B == 1 per
+    forward: per-token scales are shared over the batch otherwise).  Returns what
+    ``rowquant(attn_temporal(...).view(1, T*S, H*D))`` returns, bit for bit."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.float16:
+            raise VQError("%s must be a GPU fp16 tensor" % n)
+    if B != 1:
+        raise VQError("attn_temporal_rowquant: per-token scales are shared over the batch; B must be 1")
+    Cc = H * D
+    Kp = pad128(Cc)
+    rows = B * T * S
+    dev = q.device
+    xq = torch.empty((rows, Kp), dtype=torch.int8, device=dev)
+    sx = torch.empty(rows, dtype=torch.float32, device=dev)
+    zx = torch.empty(rows, dtype=torch.int32, device=dev)
+    R = torch.empty(rows, dtype=torch.int32, device=dev)
+    scale = float(D) ** -0.5 if scale is None else float(scale)
+    if o is not None:
+        _req(o, torch.float16, "o")
+        assert o.shape == (rows, Cc)
+    check(_L().vq_attn_temporal_rowquant(_p(q), _p(k), _p(v), _p(xq), _p(sx), _p(zx), _p(R), _p(status), _p(o), B, T, S,
+                                         H, D, ld_in, Kp, scale, _stream()), "vq_attn_temporal_rowquant")
+    return QAct(xq, sx, zx, R, Cc, 8)
+
+
 # --------------------------------------------------------------------------- misc
 def adaln_table(table: torch.Tensor, t0: torch.Tensor) -> torch.Tensor:
     """mod[J, B, C] fp32 = table[J, C] + t0[B, J*C]  (fp16 inputs); mod[j] is a contiguous [B, C]."""

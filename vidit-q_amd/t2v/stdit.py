@@ -279,6 +279,7 @@ class MultiHeadCrossAttention(nn.Module):
 # GELU inside fc2's quantizer pass (vq_gelu_rowquant) instead of the fc1 GEMM epilogue: fc1 -22 us, quantizer +13 us
 # in isolation, but 1 % SLOWER in the two-stream step (the quantizer's extra VALU lands where the other stream's
 # HBM-bound kernels run; the epilogue's lands under them).  Off unless VQ_GELU_QUANT is set.
+_ATTN_QUANT = __import__("os").environ.get("VQ_ATTN_QUANT", "1") != "0"   # attention kernels that also run the next quantizer
 _GELU_QUANT = bool(__import__('os').environ.get('VQ_GELU_QUANT'))
 
 
@@ -434,8 +435,13 @@ class STDiTBlock(nn.Module):
         else:
             qas = [l.quantize_input(x3, s, add_rows=tpe2, add_div=S) for l, s in zip((a2.q, a2.k, a2.v), svs)]
         qkv = qkv_proj(a2, qas)
-        att_o = a2.core.temporal(qkv, B, T, S, out=att_o)
-        qa = a2.proj.quantize_input(att_o.view(B, N, C), svec(a2.proj))
+        qa = None
+        if _ATTN_QUANT and svec(a2.proj) is None and isinstance(a2.proj.act_quantizer, DynamicActQuantizer) \
+                and a2.proj.act_quantizer.n_bits == 8:
+            qa = a2.core.temporal_quantized(qkv, B, T, S, status=a2.proj.status)   # attention + proj's quantizer
+        if qa is None:
+            att_o = a2.core.temporal(qkv, B, T, S, out=att_o)
+            qa = a2.proj.quantize_input(att_o.view(B, N, C), svec(a2.proj))
         ops.gemm_i8(qa, a2.proj.packed_weight(r, svec(a2.proj)), bias=a2.proj.bias_f32(), out=x2,
                     epilogue=ops.EPI_GATE_RESID, resid=x2, gate=gate_msa, rows_per_gate=N)
 
