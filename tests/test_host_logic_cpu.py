@@ -186,3 +186,37 @@ def test_get_quant_calib_data_selection():
     assert xs.shape == (5 * 4, 3) and ts.shape == (20,) and cs.shape == (20, 1, 4, 8) and ms.shape == (20, 4)
     assert ts.reshape(5, 4)[:, 0].tolist() == [1000, 800, 600, 400, 200]
     assert xs.reshape(5, 4, 3)[:, 0, 0].tolist() == [0.0, 4.0, 8.0, 12.0, 16.0]
+
+
+def test_fused_qkv_checkpoint_is_split_like_the_reference(tmp_path):
+    """OpenSORA checkpoints carry fused ``attn.qkv`` rows; the reference splits them into q | k | v thirds
+    (t2v/scripts/split_ckpt.py:3-17, stdit.py:460-481).  Same result from a fused dict and from a file."""
+    import viditq_amd  # noqa
+    from viditq_amd.t2v import STDiT
+    from viditq_amd.t2v.stdit import load_split_qkv
+    kw = dict(input_size=(4, 8, 8), depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
+    torch.manual_seed(1)
+    src = STDiT(**kw)
+    sd = src.state_dict()
+    fused = {}
+    for k, v in sd.items():
+        if ".attn.q." in k or ".attn_temp.q." in k:
+            base, kind = k.rsplit(".q.", 1)
+            fused["%s.qkv.%s" % (base, kind)] = torch.cat([sd["%s.%s.%s" % (base, n, kind)] for n in "qkv"], dim=0)
+        elif any(".%s.%s." % (a, n) in k for a in ("attn", "attn_temp") for n in "kv"):
+            continue
+        else:
+            fused[k] = v
+    assert any(k.endswith(".qkv.weight") for k in fused) and not any(".attn.q." in k for k in fused)
+    torch.manual_seed(2)
+    dst = STDiT(**kw)
+    res = load_split_qkv(dst, fused)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in sd.items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    path = tmp_path / "fused.pth"
+    torch.save(fused, str(path))
+    torch.manual_seed(3)
+    dst2 = STDiT(**kw)
+    load_split_qkv(dst2, torch.load(str(path), map_location="cpu"))
+    assert all(torch.equal(dst2.state_dict()[k], v) for k, v in sd.items())

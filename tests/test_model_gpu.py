@@ -378,6 +378,59 @@ def test_tiny_pixart_w8a8_fused_path(dev, ops):
     assert rel_l2(qnn(x, t, y, mask=mask).cpu().float(), g["fp"]) < 3e-3
 
 
+def test_ptq_calibrate_pixart_reproduces_reference_quant_params(dev, ops, tmp_path):
+    """ptq.calibrate_pixart (the t2i script's order: FP forward, weight forward, FP layer list) must produce the
+    weight grids the golden generator obtained from the REFERENCE classes with the same sequence, and a model
+    calibrated that way must reproduce the reference outputs; then the ckpt.pth round trip."""
+    import viditq_amd  # noqa
+    from viditq_amd import ptq
+    from viditq_amd.config import to_config
+    from viditq_amd.qdiff.models import QuantModel
+    from viditq_amd.t2i import PixArtMS
+    g = load_npz("tiny_pixart_w8a8.npz")
+
+    def fresh():
+        m = PixArtMS(input_size=16, depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32,
+                     dtype=torch.float16)
+        m.load_state_dict(state_dict_of(g), strict=True)
+        wq, aq = _cfgs(8)
+        aq["n_spatial_token"], aq["n_temporal_token"] = 64, 1
+        return QuantModel(m.half().to(dev).eval(), wq, aq, model_type="pixart"), wq, aq
+    qnn, wq, aq = fresh()
+    cfg = to_config({"calib_data": {"n_samples": 1, "batch_size": 2, "n_steps": 1},
+                     "quant": {"weight": {"quantizer": wq}, "activation": {"quantizer": aq}}})
+    x, y, mask, t = g["x"], g["y"].half(), g["mask"], g["t"]
+    qd = ptq.calibrate_pixart(qnn, cfg, (x, t, y, mask))
+    assert qnn.fp_layer_list == list(ptq.PIXART_FP_LAYERS)
+    ref = quant_params_of(g)
+    n_checked = 0
+    for name, (bufs, _) in qd.items():
+        for bn in ("delta_list", "zero_point_list", "delta", "zero_point"):
+            if bn in ref.get(name, {}) and bufs.get(bn) is not None and "weight_quantizer" in name:
+                a, b = bufs[bn].float().cpu(), ref[name][bn].float()
+                if "zero_point" in bn:
+                    assert (a.reshape(b.shape) - b).abs().max() <= 1, (name, bn)
+                else:
+                    assert torch.allclose(a.reshape(b.shape), b, rtol=2e-3, atol=1e-7), (name, bn)
+                n_checked += 1
+    assert n_checked >= 2 * 5 * 2                      # 2 blocks x (qkv, proj, q_linear, kv_linear, cross proj, fc1, fc2) grids
+    assert all(b.fused_ok() for b in qnn.model.blocks)
+    out = qnn(x.to(dev), t.to(dev), y.to(dev), mask=mask.to(dev))
+    assert rel_l2(out.cpu().float(), g["w8a8"]) < 5e-3
+    path = str(tmp_path / "ckpt.pth")
+    ptq.save_quant_params(qnn, path)
+    q2, _, _ = fresh()
+    q2.set_module_name_for_quantizer(q2.model)
+    q2.fp_layer_list = list(ptq.PIXART_FP_LAYERS)
+    q2.set_quant_state(True, True)
+    q2.set_layer_quant(model=q2, module_name_list=q2.fp_layer_list, quant_level="per_layer", weight_quant=False,
+                       act_quant=False, prefix="")
+    q2.set_quant_init_done("weight")
+    q2.set_quant_init_done("activation")
+    ptq.load_quant_params(q2, path)
+    assert torch.equal(q2(x.to(dev), t.to(dev), y.to(dev), mask=mask.to(dev)), out)
+
+
 def test_tiny_pixart_dpm_solver_trajectory(dev, ops):
     """The t2i sampling loop (quant_txt2img.py:130-153): DPM-Solver++ 2M, cfg 4.5, one batched (uncond | cond)
     forward of the quantized PixArt-MS per step, vs the trajectory the reference's solver produced."""

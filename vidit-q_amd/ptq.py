@@ -157,6 +157,53 @@ def calibrate(qnn: QuantModel, config, calib_data, fp_layer_list: Optional[Seque
     return qnn.get_quant_params_dict()
 
 
+PIXART_FP_LAYERS = ("x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder")
+
+
+@torch.no_grad()
+def calibrate_pixart(qnn: QuantModel, config, calib_data, batch_size: Optional[int] = None,
+                     fp_layer_list: Sequence[str] = PIXART_FP_LAYERS,
+                     smooth_quant_layer_list: Sequence[str] = ("blocks.27.mlp.fc2",), fwd_kwargs: Optional[dict] = None) -> dict:
+    """The training-free part of t2i/scripts/ptq.py (:218-318) for ``model_type: pixart``; its order differs from the
+    t2v script: (0) smooth quant - if enabled at all - is switched on together with its running statistics for the
+    listed layers only (the script hard-codes the last block's fc2, :222-226), (1) one FP forward, (2) weight grids
+    from one forward with weight quant on, (3) the FP layer list of the script (final_layer stays quantized), then
+    static activation grids over the calibration batches unless the quantizer is dynamic.  ``calib_data`` =
+    (xs, ts, cond_embs, masks); ``fwd_kwargs``: extra model kwargs (``data_info`` ...).  Returns the quant-param
+    dict; the model is left in state (True, True)."""
+    aq_params = config.quant.activation.quantizer
+    dev = next(qnn.model.parameters()).device
+    xs, ts, cs, masks = calib_data
+    bs = batch_size if batch_size is not None else config.calib_data.batch_size
+    kw = dict(fwd_kwargs or {})
+
+    def fwd(sl, mask_rows):
+        return qnn(xs[sl].to(dev), ts[sl].to(dev), cs[sl].to(dev), mask=None if masks is None else mask_rows.to(dev), **kw)
+
+    first = slice(0, bs)
+    if aq_params.get("smooth_quant") and aq_params.smooth_quant.get("enable"):
+        qnn.set_smooth_quant(smooth_quant=False, smooth_quant_running_stat=False)
+        qnn.set_layer_smooth_quant(model=qnn, module_name_list=list(smooth_quant_layer_list), smooth_quant=True,
+                                   smooth_quant_running_stat=True)
+    fwd(first, None if masks is None else masks[first])                       # :236
+    qnn.set_module_name_for_quantizer(module=qnn.model)
+    qnn.set_quant_state(True, False)                                          # :240-244
+    fwd(first, None if masks is None else masks[first])
+    qnn.set_quant_init_done("weight")
+    qnn.set_quant_state(True, True)                                           # :249-252
+    qnn.fp_layer_list = list(fp_layer_list)
+    qnn.set_layer_quant(model=qnn, module_name_list=list(fp_layer_list), quant_level="per_layer", weight_quant=False,
+                        act_quant=False, prefix="")
+    if not aq_params.get("dynamic", False):
+        if config.get("timestep_wise", False):
+            raise NotImplementedError("timestep_wise activation calibration (t2i/scripts/ptq.py:275-308)")
+        for i in range(xs.shape[0] // bs):                                    # :259-272
+            sl = slice(i * bs, (i + 1) * bs)
+            fwd(sl, None if masks is None else masks[sl][::2])
+    qnn.set_quant_init_done("activation")
+    return qnn.get_quant_params_dict()
+
+
 # --------------------------------------------------------------------------- ckpt.pth / yaml IO
 def save_quant_params(qnn: QuantModel, path: str, dtype=torch.float32) -> dict:
     """ptq.py:426-428: ``torch.save(qnn.get_quant_params_dict(), <outdir>/ckpt.pth)``."""
