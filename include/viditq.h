@@ -167,7 +167,10 @@ int vq_gemm_i8_batched(const int8_t* xq, const float* sx, const int32_t* zx, con
  * multiples of 8); k, v use kv_*_stride, o uses o_*_stride.  With kv_off
  * (device int32 [n_seq+1], nullable) sequence i attends to kv rows
  * [kv_off[i], kv_off[i+1]) at kv_tok_stride (block-diagonal / varlen cross
- * attention) and kv_seq_stride / Lk are ignored.  D in {16, 32, 64, 72}.
+ * attention), kv_seq_stride is ignored and Lk is an upper bound on every sequence's
+ * kv length if the caller knows one (0 = unknown): D = 72 with a bound <= 128 (the
+ * <= 120 prompt tokens of STDiT) runs a kernel that keeps K and V^T of a head in
+ * registers.  D in {16, 32, 64, 72}.
  */
 int vq_attn_fwd(const void* q, const void* k, const void* v, void* o,
                 int n_seq, int Lq, int Lk, int H, int D,

@@ -327,6 +327,38 @@ def test_attn_fwd_cross_varlen(ops, dev):
     assert rel_l2(o.cpu().float(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("B,Nq,H,lens", [(1, 16384, 16, [120]), (1, 1000, 16, [80]), (3, 203, 8, [17, 120, 1]),
+                                         (2, 64, 16, [128, 33]), (1, 4096, 16, [16])])
+def test_attn_cross_short_kv_register_kernel(ops, dev, B, Nq, H, lens):
+    """Cross attention with a host-known bound Lk <= 128 on the kv length (head_dim 72, H % 8 == 0) runs the kernel
+    that keeps K / V^T of a head in registers; same oracle (fp32 softmax attention over each sample's own prompt
+    rows) and tolerance as the general kernel, ragged query counts and every key-tile fill level included."""
+    D = 72
+    Cc = H * D
+    q = h16(B * Nq, Cc, seed=Nq).to(dev)
+    kv = h16(sum(lens), 2 * Cc, seed=2).to(dev)
+    offs = [0]
+    for L in lens:
+        offs.append(offs[-1] + L)
+    off = torch.tensor(offs, dtype=torch.int32, device=dev)
+    o = torch.full_like(q, float("nan"))
+    ops.attn_fwd(q, kv, kv[:, Cc:], o, B, Nq, max(lens), H, D, Nq * Cc, Cc, 0, 2 * Cc, Nq * Cc, Cc, kv_off=off)
+    o_gen = torch.empty_like(q)                                    # the general kernel (bound unknown)
+    ops.attn_fwd(q, kv, kv[:, Cc:], o_gen, B, Nq, 0, H, D, Nq * Cc, Cc, 0, 2 * Cc, Nq * Cc, Cc, kv_off=off)
+    rows = torch.arange(0, Nq, max(1, Nq // 256))
+    qs = q.cpu().reshape(B, Nq, H, D)[:, rows]
+    outs = []
+    for b, Lb in enumerate(lens):
+        kb = kv[offs[b]:offs[b] + Lb, :Cc].cpu().reshape(1, Lb, H, D)
+        vb = kv[offs[b]:offs[b] + Lb, Cc:].cpu().reshape(1, Lb, H, D)
+        outs.append(_attn_ref(qs[b:b + 1], kb, vb, D ** -0.5))
+    ref = torch.cat(outs).reshape(B * len(rows), Cc)
+    got = o.cpu().float().reshape(B, Nq, Cc)[:, rows].reshape(B * len(rows), Cc)
+    assert torch.isfinite(o).all()
+    assert rel_l2(got, ref) < 1e-3
+    assert rel_l2(o.cpu().float(), o_gen.cpu().float()) < 1e-3
+
+
 @pytest.mark.parametrize("B,T,S,H,D", [(1, 16, 64, 16, 72), (2, 4, 9, 4, 16), (1, 16, 1024, 16, 72)])
 def test_attn_temporal(ops, dev, B, T, S, H, D):
     Cc = H * D

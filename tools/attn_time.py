@@ -28,6 +28,11 @@ o = torch.empty_like(q)
 t = timeit(lambda: ops.attn_fwd(q, kv, kv[:, 1152:], o, 1, 16384, 0, H, D, 16384 * 1152, 1152, 0, 2304, 16384 * 1152, 1152,
                                 kv_off=off), iters=20)
 print("cross 16384 x 120: %.1f us" % (t * 1e6))
+for Lk in (120, 80):
+    off = torch.tensor([0, Lk], dtype=torch.int32, device=dev)
+    t = timeit(lambda: ops.attn_fwd(q, kv[:Lk], kv[:Lk, 1152:], o, 1, 16384, Lk, H, D, 16384 * 1152, 1152, 0, 2304, 16384 * 1152,
+                                    1152, kv_off=off), iters=20)
+    print("cross 16384 x %d, bound known (register kernel): %.1f us" % (Lk, t * 1e6))
 qkv = torch.randn(16384, 3456, generator=g).half().to(dev)
 o = torch.empty((16384, 1152), dtype=torch.float16, device=dev)
 t = timeit(lambda: ops.attn_temporal(qkv, qkv[:, 1152:], qkv[:, 2304:], o, 1, 16, 1024, H, D, 3456, 1152), iters=20)

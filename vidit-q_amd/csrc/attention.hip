@@ -936,6 +936,185 @@ __global__ __launch_bounds__(64 * NW, NQ == 2 ? 1 : 8 / NW) void attn_fwd8_kerne
 }
 
 // ---------------------------------------------------------------------------
+// attn_cross_reg_kernel: cross attention against a SHORT key/value sequence (<= 128 keys: the <= 120 prompt tokens of
+// STDiT), head_dim 72.  attn_fwd_kernel moved the algorithmic 78 MB in 42 us (1.9 TB/s): 2048 workgroups each staged
+// the same K/V tile pair through LDS, read their queries, and ran two short flash iterations behind barriers.  Here
+// K and V^T of ONE head live in the REGISTERS of one wave for the whole kernel, already in MFMA operand form:
+//   S^T[key][query] = K Q^T : A = K  (16 keys  x 32 dims per lane group: 2 x 16x16x32 + 1 x 16x16x16 for dims 64..71)
+//   O^T[dim][query] = V^T P^T: A = V^T (16 dims x 32 keys): 16x16x32; the k-slot order of a 32-key step is
+//       slot (g4, e) <-> key (2*kp + (e >> 2)) * 16 + 4*g4 + (e & 3), i.e. exactly the two S^T accumulator quads
+//       the lane already holds for key tiles 2*kp and 2*kp + 1: P^T needs no shuffle, only exp2 and cvt.
+// A workgroup = 8 waves = 8 consecutive heads walking the same 16-query sub-tiles (their 144-byte row segments
+// share cache lines), persistent over sub-tiles; the next sub-tile's q fragments are requested as soon as QK^T is issued.  No LDS in the loop,
+// no barriers; V^T is transposed once per wave through a private LDS region.  All keys of a row are present at once,
+// so the softmax is the plain two-pass form (no running rescale).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_cross_reg_kernel(AttnArgs a) {
+    constexpr int D = 72, NKT = 8, VROWB = 152;    // V staging row stride: 38 dwords -> the four lane groups hit different banks
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, g4 = lane >> 4;
+    const int h = blockIdx.y * 8 + wave, seq = blockIdx.z;
+    int kv_len = a.Lk;
+    const half_t* kbase;
+    const half_t* vbase;
+    if (a.kv_off) {
+        const int o0 = a.kv_off[seq];
+        kv_len = a.kv_off[seq + 1] - o0;
+        kbase = a.k + (long)o0 * a.kv_tok_stride + h * D;
+        vbase = a.v + (long)o0 * a.kv_tok_stride + h * D;
+    } else {
+        kbase = a.k + (long)seq * a.kv_seq_stride + h * D;
+        vbase = a.v + (long)seq * a.kv_seq_stride + h * D;
+    }
+    kv_len = kv_len < 16 * NKT ? kv_len : 16 * NKT;   // host guarantees <= 128
+    const half8 z8 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    const half4 z4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+
+    // ---- V of this head -> private LDS region (row-major, coalesced 16-byte chunks), then V^T operand fragments
+    uint8_t* vreg = smem + wave * (16 * NKT * VROWB);
+    {
+        constexpr int CH = D / 8, NCH = 16 * NKT * CH;           // 9 chunks per key row
+#pragma unroll
+        for (int i = 0; i < (NCH + 63) / 64; ++i) {
+            const int c = lane + i * 64;
+            const int key = c / CH, ch = c - key * CH;
+            int4v val = {0, 0, 0, 0};
+            if (c < NCH && key < kv_len) val = *reinterpret_cast<const int4v*>(vbase + (long)key * a.kv_tok_stride + ch * 8);
+            if (c < NCH) {
+                *reinterpret_cast<int2v*>(vreg + key * VROWB + ch * 16) = int2v{val[0], val[1]};
+                *reinterpret_cast<int2v*>(vreg + key * VROWB + ch * 16 + 8) = int2v{val[2], val[3]};
+            }
+        }
+    }
+    // K operand fragments straight from global: lane = key lq of tile kt, 8 dims per 32-dim step
+    half8 kf[NKT][2];
+    half4 kt4[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int key = kt * 16 + lq;
+        const half_t* kr = kbase + (long)(key < kv_len ? key : 0) * a.kv_tok_stride;
+        const bool ok = key < kv_len;
+        kf[kt][0] = ok ? *reinterpret_cast<const half8*>(kr + 8 * g4) : z8;
+        kf[kt][1] = ok ? *reinterpret_cast<const half8*>(kr + 32 + 8 * g4) : z8;
+        kt4[kt] = (ok && g4 < 2) ? *reinterpret_cast<const half4*>(kr + 64 + 4 * g4) : z4;
+    }
+    // (the LDS writes above are this wave's own: in-order LDS, no workgroup barrier needed)
+    half8 vf[5][4];
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
+        const int d = dt * 16 + lq;
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = (2 * kp + (e >> 2)) * 16 + 4 * g4 + (e & 3);
+                vf[dt][kp][e] = d < D ? *reinterpret_cast<const half_t*>(vreg + key * VROWB + d * 2) : (half_t)0.f;
+            }
+    }
+
+    // ---- persistent walk over 16-query sub-tiles
+    const int nsub = (a.Lq + 15) / 16;
+    const half_t* qseq = a.q + (long)seq * a.q_seq_stride + h * D;
+    half_t* oseq = a.o + (long)seq * a.o_seq_stride + h * D;
+    half8 qa, qb;
+    half4 qc;
+    auto load_q = [&](int st, half8& x0, half8& x1, half4& x2) {
+        int qi = st * 16 + lq;
+        qi = qi < a.Lq ? qi : a.Lq - 1;
+        const half_t* qr = qseq + (long)qi * a.q_tok_stride;
+        x0 = *reinterpret_cast<const half8*>(qr + 8 * g4);
+        x1 = *reinterpret_cast<const half8*>(qr + 32 + 8 * g4);
+        x2 = g4 < 2 ? *reinterpret_cast<const half4*>(qr + 64 + 4 * g4) : z4;
+    };
+    int st = blockIdx.x;
+    if (st < nsub) load_q(st, qa, qb, qc);
+    for (; st < nsub; st += gridDim.x) {
+        const int nst = st + (int)gridDim.x;
+        float4v sc[NKT];
+        float m = -INFINITY;
+        // MFMA HAZARD (measured, tools/dbg_cross.py): a 16x16x16 MFMA that takes the result of a 16x16x32 MFMA as
+        // its SrcC right behind it (or the other way round) reads a STALE accumulator on gfx950 with this compiler -
+        // the wait states inserted between dependent MFMAs of different shapes are too few (32 cycles of s_nop fix
+        // it; same-shape chains are fine).  So the two shapes are issued in separate phases: all 32-dim steps of
+        // the eight key tiles, then the eight 16-dim tails, each >= 7 MFMAs behind the instruction it accumulates on
+        // (skipping the empty key tiles of short prompts behind wave-uniform branches was slower: 38.7 vs 35.2 us).
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            float4v s = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][0], qa, s, 0, 0, 0);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][1], qb, s, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kt4[kt], qc, sc[kt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kt * 16 + 4 * g4 + r >= kv_len) sc[kt][r] = -INFINITY;
+                m = fmaxf(m, sc[kt][r]);
+            }
+        if (nst < nsub) load_q(nst, qa, qb, qc);       // next sub-tile's fragments land during softmax and P.V
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float m_use = (m == -INFINITY) ? 0.f : m;
+        float psum = 0.f;
+        half8 pf[4];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f((sc[kt][r] - m_use) * a.c);
+                psum += p;
+                pf[kt >> 1][(kt & 1) * 4 + r] = (half_t)p;
+            }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        const float inv = psum > 0.f ? __fdiv_rn(1.0f, psum) : 0.f;
+        const int qi = st * 16 + lq;
+        half_t* orow = oseq + (long)qi * a.o_tok_stride;
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            float4v o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt][kp], pf[kp], o, 0, 0, 0);
+            const int d0 = dt * 16 + 4 * g4;
+            if (d0 < D && qi < a.Lq) {
+                half4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[r] * inv);
+                *reinterpret_cast<half4*>(orow + d0) = ov;
+            }
+        }
+    }
+}
+
+static int launch_cross_reg(const AttnArgs& a, hipStream_t st) {
+    constexpr int LDS = 8 * 128 * 152;
+    auto k = attn_cross_reg_kernel;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    static int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    const int groups = a.n_seq * (a.H / 8);            // (sequence, 8-head group) pairs share the CUs
+    const int nsub = (a.Lq + 15) / 16;
+    int gx = ncu / groups;
+    gx = gx < 1 ? 1 : (gx > nsub ? nsub : gx);
+    hipLaunchKernelGGL(k, dim3(gx, a.H / 8, a.n_seq), dim3(512), LDS, st, a);
+    return vq_check_launch();
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 template <int D, int NW, int NQ = 1>
@@ -970,6 +1149,9 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     // second-generation kernel for long key sequences; short ones (cross attention: <= 2 key tiles, where the
     // per-workgroup prologue dominates) and short query sequences keep the first kernel.  VQ_ATTN_V1 forces it.
     static const bool old_kernel = getenv("VQ_ATTN_V1") != nullptr;
+    // short key/value sequences with a known bound (cross attention over <= 128 prompt tokens): K, V^T in registers
+    static const bool no_reg = getenv("VQ_ATTN_CROSS_REG") && atoi(getenv("VQ_ATTN_CROSS_REG")) == 0;   // measurement switch
+    if (D == 72 && !old_kernel && !no_reg && a.Lk > 0 && a.Lk <= 128 && a.H % 8 == 0 && a.Lq >= 64) return launch_cross_reg(a, st);
     if (!old_kernel && !a.kv_off && a.Lk > 128 && a.Lq >= 96)
     {
         static const bool two = getenv("VQ_ATTN_NQ2") != nullptr;      // measurement switch

@@ -94,6 +94,8 @@ class QuantAttention(nn.Module):
         C = self.num_heads * self.head_dim
         if out is None:
             out = torch.empty_like(q)
-        ops.attn_fwd(q, kv, kv[:, C:], out, B, Nq, 0, self.num_heads, self.head_dim, Nq * q.stride(0), q.stride(0),
-                     0, kv.stride(0), Nq * out.stride(0), out.stride(0), kv_off=kv_off, scale=self.scale)
+        # Lk with kv_off = a bound on every sample's kv length (here: all rows of kv): short prompts take the
+        # register-resident kernel
+        ops.attn_fwd(q, kv, kv[:, C:], out, B, Nq, kv.shape[0], self.num_heads, self.head_dim, Nq * q.stride(0),
+                     q.stride(0), 0, kv.stride(0), Nq * out.stride(0), out.stride(0), kv_off=kv_off, scale=self.scale)
         return out
