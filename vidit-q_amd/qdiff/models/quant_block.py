@@ -94,8 +94,9 @@ class QuantAttention(nn.Module):
         C = self.num_heads * self.head_dim
         if out is None:
             out = torch.empty_like(q)
-        # Lk with kv_off = a bound on every sample's kv length (here: all rows of kv): short prompts take the
-        # register-resident kernel
-        ops.attn_fwd(q, kv, kv[:, C:], out, B, Nq, kv.shape[0], self.num_heads, self.head_dim, Nq * q.stride(0),
+        # Lk with kv_off = a bound on every sample's kv length (the longest prompt when the offsets came from
+        # seq_offsets, else all rows of kv): short prompts take the register-resident kernel
+        bound = int(getattr(kv_off, "max_len", 0)) or kv.shape[0]
+        ops.attn_fwd(q, kv, kv[:, C:], out, B, Nq, bound, self.num_heads, self.head_dim, Nq * q.stride(0),
                      q.stride(0), 0, kv.stride(0), Nq * out.stride(0), out.stride(0), kv_off=kv_off, scale=self.scale)
         return out

@@ -249,6 +249,7 @@ def seq_offsets(lens, device) -> torch.Tensor:
         if len(_OFFSETS) > 4096:
             _OFFSETS.clear()
         off = _OFFSETS[key] = torch.tensor(np.concatenate([[0], np.cumsum(key[0])]), dtype=torch.int32).to(device)
+        off.max_len = max(key[0]) if key[0] else 0      # host-side bound for kernels specialised on short sequences
     return off
 
 
