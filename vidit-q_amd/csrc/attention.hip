@@ -416,14 +416,16 @@ struct TempQArgs {
     float c;
 };
 
-template <int D>
+// HC: head count known at compile time (16 = STDiT-XL; 0 = take a.H): the chunk -> (tensor, row, piece) divisions of
+// the staging loops are by H * D / 8 and cost ~45 VALU instructions each with a run-time divisor
+template <int D, int HC>
 __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) {
     constexpr int KS = (D + 15) / 16;              // 16-dim k-steps of QK^T = 16-dim row tiles of O^T
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = head
     const int tq = lane & 15, g4 = lane >> 4;      // MFMA 16x16x16: lane = (row or column tq, k / row group g4)
-    const int H = a.H, C = H * D, nthr = 64 * H;
+    const int H = HC ? HC : a.H, C = H * D, nthr = 64 * H;
     const int RS = C * 2 + 16;                     // LDS row stride (odd number of 16-byte slots)
     const int TILE = 16 * RS;
     const int RCH = C / 8;                         // 16-byte chunks per tensor row
@@ -560,7 +562,10 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
             ex_min[wave * 16 + tq] = vmin;
             ex_max[wave * 16 + tq] = vmax;
         }
-        __syncthreads();                           // row statistics visible; every wave is done with the q | k | v tiles
+        // (raw barriers in the loop: __syncthreads() also waits for vmcnt(0), i.e. for the rows just requested for the
+        //  position after next - that serialised every iteration behind one HBM round trip)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // row statistics visible; every wave is done with the q | k | v tiles
         if (has_next) {
             store_qkv(tx);                         // next position's rows (visible after the barrier below) ...
             if (npos_next + (int)gridDim.x < npos) load_qkv(npos_next + (int)gridDim.x, tx);   // ... and the one after it
@@ -594,7 +599,8 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
         cs += __shfl_xor(cs, 16);
         cs += __shfl_xor(cs, 32);
         if (lane < 16) ex_sum[wave * 16 + tq] = cs;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         // ---- codes out as whole 16-byte chunks (pad columns [C, Kp) zeroed like the row quantizers do); the next
         //      iteration touches codes / ex_sum only after its own first barrier, which every thread reaches after this
         const int kch = a.Kp / 16, cch = C / 16;
@@ -1228,9 +1234,12 @@ template <int D>
 static int launch_temporal_quant(const TempQArgs& a, hipStream_t st) {
     const int C = a.H * D;
     const int LDS = 3 * 16 * (C * 2 + 16) + 16 * (C + 16) + 3 * 1024;
-    auto k = attn_temporal_quant_kernel<D>;
-    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              3 * 16 * (16 * 72 * 2 + 16) + 16 * (16 * 72 + 16) + 3 * 1024);
+    auto k = a.H == 16 ? attn_temporal_quant_kernel<D, 16> : attn_temporal_quant_kernel<D, 0>;
+    constexpr int LDS_MAX = 3 * 16 * (16 * 72 * 2 + 16) + 16 * (16 * 72 + 16) + 3 * 1024;
+    static hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_temporal_quant_kernel<D, 0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    static hipError_t e = e0 != hipSuccess ? e0 : hipFuncSetAttribute(reinterpret_cast<const void*>(attn_temporal_quant_kernel<D, 16>),
+                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
     if (e != hipSuccess) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
