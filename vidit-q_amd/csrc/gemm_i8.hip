@@ -524,7 +524,8 @@ struct ColParams {
     int nzw, cs;
 };
 template <int BN>
-__device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int n0, int tid_in = -1) {
+__device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int n0, int tid_in = -1,
+                                                          const float* gate_row = nullptr) {
     ColParams c{0.f, 0.f, 0, 0};
     const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     const int gn = n0 + tx;
@@ -533,6 +534,11 @@ __device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int
         c.nzw = -a.zw[gn];
         c.cs = a.cs[gn];
         c.b = a.bias ? a.bias[gn] : 0.f;
+        if (gate_row) {                                // gate * (sx*sw*t + b): folded into the per-channel terms
+            const float g = gate_row[gn];
+            c.sw *= g;
+            c.b *= g;
+        }
     }
     return c;
 }
@@ -583,11 +589,24 @@ __device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t
     }
 }
 
+// VQ_EPI_GATE_RESID: the gate row (sample) of a token tile when all its rows belong to ONE sample, else nullptr.
+// With it the gate is folded into the staged per-channel scale and bias, and the store loop only adds the residual:
+// the two 16-byte gate loads per lane in each of its 18 iterations cost 5 us per N = K = 1152 launch.
+template <int BM>
+__device__ __forceinline__ const float* ring_tile_gate_row(const GemmArgs& a, int m0) {
+    if (a.epilogue != VQ_EPI_GATE_RESID) return nullptr;
+    const int mlast = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
+    const int s0 = __builtin_amdgcn_readfirstlane(m0 / a.rows_per_gate);
+    const int s1 = __builtin_amdgcn_readfirstlane(mlast / a.rows_per_gate);
+    return s0 == s1 ? a.gate + (size_t)s0 * a.N : nullptr;
+}
+
 // Stage both parameter blocks (called once all fragment reads of the main loop are issued; the blocks lie
 // past the end of every ring, so no barrier is needed before writing them, only before reading them).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
-__device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* smem, int m0, int n0, int tid_in = -1) {
-    const ColParams colp = ring_load_col_params<BN>(a, n0, tid_in);
+__device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* smem, int m0, int n0, int tid_in = -1,
+                                                  const float* gate_row = nullptr) {
+    const ColParams colp = ring_load_col_params<BN>(a, n0, tid_in, gate_row);
     const RowParams rowp = ring_load_row_params<BM>(a, m0, tid_in);
     ring_park_col_params<BM, BN, WAVES_M, WAVES_N, PAD>(colp, smem, tid_in);
     ring_park_row_params<BM, BN, WAVES_M, WAVES_N, PAD>(rowp, smem, tid_in);
@@ -598,7 +617,8 @@ __device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* sm
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16>
 __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                                               int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
-                                              long long* ts = nullptr, int tid_in = -1) {
+                                              long long* ts = nullptr, int tid_in = -1, bool gate_folded = false) {
+    // gate_folded (workgroup-uniform): VQ_EPI_GATE_RESID with the gate already inside the staged scale / bias
     // tid_in: the persistent kernel passes an opaque copy of threadIdx.x per tile so that the address arithmetic
     // below is not hoisted out of its tile loop (and kept in registers through the main loop)
     constexpr int NW = WAVES_M * WAVES_N;
@@ -706,7 +726,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
         const bool full = n + 8 <= a.N;               // N % 4 == 0: otherwise exactly 4 valid
         if constexpr (EPI == VQ_EPI_GATE_RESID || EPI == VQ_EPI_RESID) {
             const half8 rr = rres[it];
-            if constexpr (EPI == VQ_EPI_GATE_RESID) {
+            if (EPI == VQ_EPI_GATE_RESID && !gate_folded) {
                 const float* g = a.gate + (size_t)(m / a.rows_per_gate) * a.N + n;
                 const float4v g0 = *reinterpret_cast<const float4v*>(g);
                 const float4v g1 = full ? *reinterpret_cast<const float4v*>(g + 4) : float4v{0, 0, 0, 0};
@@ -1139,9 +1159,10 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
     if ((ABL & 32) != 0) __builtin_amdgcn_s_setprio(0);
 #undef VQ_WIDE_STEP
     if (ts) ts[2] = __builtin_readcyclecounter();
-    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0);
+    const float* gate_row = EPI == VQ_EPI_GATE_RESID ? ring_tile_gate_row<BM>(a, m0) : nullptr;
+    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0, -1, gate_row);
     __syncthreads();
-    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts);
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts, -1, gate_row != nullptr);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
