@@ -293,7 +293,8 @@ def _attn_ref(q, k, v, scale):
     return torch.einsum("nhqk,nkhd->nqhd", a, v.float())
 
 
-@pytest.mark.parametrize("n_seq,L,H,D", [(2, 1024, 2, 72), (3, 100, 4, 16), (1, 256, 2, 64), (2, 65, 3, 32)])
+@pytest.mark.parametrize("n_seq,L,H,D", [(2, 1024, 2, 72), (3, 100, 4, 16), (1, 256, 2, 64), (2, 65, 3, 32),
+                                         (5, 96, 8, 72), (300, 128, 16, 72)])   # last two: short fixed-length K/V -> register kernel
 def test_attn_fwd_self(ops, dev, n_seq, L, H, D):
     Cc = H * D
     qkv = h16(n_seq * L, 3 * Cc, scale=1.0, seed=L + D).to(dev)
