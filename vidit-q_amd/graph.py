@@ -40,7 +40,9 @@ class StepGraph:
                 self._forward(timestep_id)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread_local: with a process group alive (N > 1) the RCCL watchdog thread polls events while we capture; in
+        # the default 'global' mode such a call from ANOTHER thread would invalidate the capture
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.cond, self.uncond = self._forward(timestep_id)
 
     def _forward(self, t_id):
