@@ -1067,13 +1067,14 @@ __global__ __launch_bounds__(512) void attn_cross_reg_kernel(AttnArgs a) {
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
         const float m_use = (m == -INFINITY) ? 0.f : m;
+        const float nmc = -m_use * a.c;                // exp2(s*c - m*c): one fma per score instead of sub + mul
         float psum = 0.f;
         half8 pf[4];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f((sc[kt][r] - m_use) * a.c);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], a.c, nmc));
                 psum += p;
                 pf[kt >> 1][(kt & 1) * 4 + r] = (half_t)p;
             }
