@@ -54,7 +54,7 @@ def _worker(rank, world, port, ret):
                 pw = ops.PackedWeight(torch.randint(-128, 127, (N, Kp), generator=g, dtype=torch.int8),
                                       torch.rand(N, generator=g), torch.randint(-128, 127, (N,), generator=g, dtype=torch.int32),
                                       torch.randint(-9999, 9999, (N,), generator=g, dtype=torch.int32), N, K, Kp, 8)
-                layer._packed[(0, 8)] = (pw, wq.delta, layer.weight._version)
+                layer.install_packed(0, pw)
         nbytes = shard.broadcast_quant_state(qnn, rank, src=0)
         # every rank now holds identical grids and packed weights: checksum of checksums
         acc = torch.zeros(1, dtype=torch.float64)

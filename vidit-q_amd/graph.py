@@ -36,7 +36,12 @@ class StepGraph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):                      # warm caches (mask select, packed weights, MIOpen find)
+            # first pass on ONE stream: it packs weights and fills the module-level caches (fused qkv weights, prompt
+            # K/V, mask selection).  Run on two streams that pass would let the cond chain read a cached tensor that the
+            # uncond chain's stream is still producing - and such a tensor would persist into the captured graph
+            self._forward(timestep_id, serial=True)
+            side.synchronize()
+            for _ in range(warmup):                      # then the capture's own launch pattern
                 self._forward(timestep_id)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
@@ -45,9 +50,9 @@ class StepGraph:
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.cond, self.uncond = self._forward(timestep_id)
 
-    def _forward(self, t_id):
+    def _forward(self, t_id, serial=False):
         q = self.qnn
-        if self.cfg_split and self.two_streams:
+        if self.cfg_split and self.two_streams and not serial:
             cur = torch.cuda.current_stream()
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
@@ -77,6 +82,7 @@ class GraphedSampler:
         self.qnn, self.yc, self.yu, self.mask = qnn, y_cond, y_uncond, mask
         self.two_streams = two_streams
         self.graphs: Dict[Tuple[int, Hashable], StepGraph] = {}
+        self._epoch = None
 
     def _range_of(self, t_id: int) -> int:
         from .qdiff.models.quant_layer import find_interval
@@ -88,6 +94,12 @@ class GraphedSampler:
     def forward_pair(self, x, t_id: int, mp_key: Hashable = None):
         """``mp_key``: whatever identifies the current per-layer bit-width / FP-layer state (the caller has
         already applied it to ``qnn``); a new key captures a new graph."""
+        from .qdiff.models.quant_layer import PACK_EPOCH
+        if self._epoch != PACK_EPOCH[0]:
+            # some layer dropped its packed weights since the last capture (invalidate_packed / set_quant_params_dict):
+            # the captured graphs reference the freed buffers - drop them, the next call captures afresh
+            self.graphs.clear()
+            self._epoch = PACK_EPOCH[0]
         r = (self._range_of(t_id), mp_key)
         g = self.graphs.get(r)
         if g is None:

@@ -29,6 +29,10 @@ from ..quantizer.dynamic_quantizer import DynamicActQuantizer
 logger = logging.getLogger(__name__)
 
 
+PACK_EPOCH = [0]   # bumped whenever any layer drops its packed weights: captured HIP graphs hold their addresses
+ANY_S = object()   # marks a packed-weight entry that was packed elsewhere (matches any smoothing vector)
+
+
 def find_interval(timerange, timestep_id):
     """qdiff/models/quant_layer.py:15-19."""
     for index, interval in enumerate(timerange):
@@ -124,6 +128,10 @@ class QuantLayer(nn.Module):
             alpha = alpha[r]
         return r, alpha
 
+    def _alpha_of(self, r):
+        alpha = self.smooth_quant_alpha
+        return alpha[r] if isinstance(alpha, (list, tuple, ListConfig)) else alpha
+
     def _update_running_act_scale(self, input, r):
         """momentum act-scale statistic during calibration (quant_layer.py:118-126, :147-154)."""
         cur = input.abs().amax(dim=-2).float().mean(dim=0, keepdim=True)
@@ -152,28 +160,44 @@ class QuantLayer(nn.Module):
     def invalidate_packed(self):
         self._packed = {}
         self._bias_f32 = None
+        PACK_EPOCH[0] += 1
 
     def _can_pack(self) -> bool:
         wq = self.weight_quantizer
         return (self.fwd_func is F.linear and wq.init_done and wq.delta is not None
                 and wq.per_group == "channel" and wq.n_bits <= 8)
 
+    def _act_scale_version(self):
+        a = getattr(self.act_quantizer, "act_scale", None)
+        return None if a is None else (a.data_ptr(), a._version)
+
     def packed_weight(self, r: int = 0, s: Optional[torch.Tensor] = None) -> ops.PackedWeight:
         """int8/int4 codes of W*s_r on the grid the reference uses: ALWAYS ``weight_quantizer.delta``
         = delta_list[bit_idx at PTQ, range 0] (base_quantizer.py:126), clamped at the
-        CURRENT n_bits."""
+        CURRENT n_bits.  An entry is valid for the grid, the weight version AND the smoothing vector it was
+        packed with (``s`` is the cached tensor of :meth:`smooth_vector`, which is replaced whenever the
+        act-scale statistic changes - also in place, quant_layer.py:122-126 - so a stale W*s is never reused);
+        entries installed from a broadcast (shard.py) match any ``s`` of the act-scale version they came with."""
         wq = self.weight_quantizer
+        if s is None and self.smooth_quant and self.channel_wise_scale_type != "dynamic":
+            s = self.smooth_vector(r, self._alpha_of(r))        # a smoothed layer is never packed without its s
         key = (r, wq.n_bits)
         ent = self._packed.get(key)
-        if ent is not None and ent[1] is wq.delta and ent[2] == self.weight._version:
+        if (ent is not None and ent[1] is wq.delta and ent[2] == self.weight._version
+                and (ent[3] is s or (ent[3] is ANY_S and ent[4] == self._act_scale_version()))):
             return ent[0]
         W = self.weight.detach()
         if W.dtype != torch.float16:
             W = W.half()
         pw = ops.pack_weight(W.contiguous(), wq.delta.reshape(-1).float(), wq.zero_point.reshape(-1).float(),
                              wq.n_bits, s=None if s is None else s.reshape(-1).float().contiguous())
-        self._packed[key] = (pw, wq.delta, self.weight._version)
+        self._packed[key] = (pw, wq.delta, self.weight._version, s, self._act_scale_version())
         return pw
+
+    def install_packed(self, r: int, pw: "ops.PackedWeight"):
+        """Adopt a weight packed elsewhere (rank 0 of a sharded job) for time-range ``r``."""
+        self._packed[(r, pw.n_bits)] = (pw, self.weight_quantizer.delta, self.weight._version, ANY_S,
+                                        self._act_scale_version())
 
     def bias_f32(self):
         if self.bias is None:
@@ -187,14 +211,23 @@ class QuantLayer(nn.Module):
         if not self.smooth_quant:
             return None
         if self.channel_wise_scale_type == "dynamic":
+            if input is None:
+                raise RuntimeError("channel_wise_scale_type 'dynamic' derives the smoothing vector from the live input "
+                                   "(quant_layer.py:116-117): such a layer runs on the simulation route, not on the "
+                                   "fused integer path")
             return self.channel_wise_scale(r, alpha, input).reshape(-1).contiguous()
         key = ("s", r)
         ent = self._packed.get(key)
         aq = self.act_quantizer
-        if ent is not None and ent[1] is aq.act_scale and ent[2] == self.weight._version:
+        # act_scale is updated IN PLACE by the running statistic (quant_layer.py:122-126): identity alone would
+        # keep a vector computed from an older statistic, so the tensor's version counter is part of the key
+        ver = self._act_scale_version()
+        if ent is not None and ent[1] is aq.act_scale and ent[2] == self.weight._version and ent[3] == ver \
+                and ent[4] == alpha:
             return ent[0]
         s = self.channel_wise_scale(r, alpha).reshape(-1).contiguous()
-        self._packed[key] = (s, aq.act_scale, self.weight._version)
+        # channel_wise_scale may itself patch zeros of act_scale in place (:128-133): key on the version AFTER it
+        self._packed[key] = (s, aq.act_scale, self.weight._version, self._act_scale_version(), alpha)
         return s
 
     # ------------------------------------------------------------------ activation views
@@ -209,6 +242,8 @@ class QuantLayer(nn.Module):
             return False
         if not self._can_pack():
             return False
+        if self.smooth_quant and getattr(self, "channel_wise_scale_type", None) == "dynamic":
+            return False   # s depends on the live input: W*s cannot be packed ahead (simulation route re-derives it)
         aq = self.act_quantizer
         if isinstance(aq, DynamicActQuantizer):
             return aq.per_group == "token" and aq.n_bits <= 8

@@ -97,7 +97,7 @@ def _install_quant_state(qnn: QuantModel, tensors: Dict[str, torch.Tensor]):
         layer = layers[lname]
         K = layer.weight.shape[1]
         pw = ops.PackedWeight(f["wq"], f["sw"], f["zw"], f["cs"], f["sw"].numel(), K, ops.pad128(K), nb)
-        layer._packed[(r, nb)] = (pw, layer.weight_quantizer.delta, layer.weight._version)
+        layer.install_packed(r, pw)
 
 
 def prepack(qnn: QuantModel):

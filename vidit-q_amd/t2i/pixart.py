@@ -25,8 +25,8 @@ from .. import ops
 from ..qdiff.models.quant_block import QuantAttention
 from ..qdiff.models.quant_layer import QuantLayer
 from ..qdiff.quantizer.dynamic_quantizer import DynamicActQuantizer
-from ..t2v.stdit import (CaptionEmbedder, Mlp, MultiHeadCrossAttention, T2IFinalLayer, TimestepEmbedder, approx_gelu,
-                         get_1d_sincos_pos_embed_from_grid, seq_offsets, t2i_modulate)
+from ..t2v.stdit import (CaptionEmbedder, Mlp, MultiHeadCrossAttention, STDiTBlock, T2IFinalLayer, TimestepEmbedder,
+                         approx_gelu, get_1d_sincos_pos_embed_from_grid, seq_offsets, t2i_modulate)
 
 
 def get_2d_sincos_pos_embed(embed_dim, grid_size, pe_interpolation=1.0, base_size=16):
@@ -122,6 +122,11 @@ class PixArtMSBlock(nn.Module):
                 return False
             if not isinstance(m.act_quantizer, DynamicActQuantizer) and m.act_quantizer.per_group:
                 return False
+            if getattr(m, "smooth_quant_running_stat", False):
+                # the released t2i script leaves the running act-scale statistic ON for blocks.27.mlp.fc2 at inference
+                # (quant_txt2img.py:297-300): that layer re-derives s from every input, which is QuantLayer.forward's
+                # job (host-visible statistics) - such a block takes the reference data flow, layer by layer
+                return False
         return True
 
     def forward(self, x, y, t, mask=None, HW=None, **kwargs):
@@ -151,8 +156,7 @@ class PixArtMSBlock(nn.Module):
         x3 = x2.view(B, N, C)
         st = a1.qkv.status
         r, s = sv(a1.qkv)
-        qa = ops.ln_modulate_rowquant(x3, shift_msa, scale_msa, 1e-6, smooth=[s], n_bits=a1.qkv.act_quantizer.n_bits,
-                                      status=st)[0]
+        qa = STDiTBlock._ln_quant(x3, shift_msa, scale_msa, (a1.qkv,), [s], st)[0]   # dynamic or calibrated static grid
         qkv = ops.gemm_i8(qa, a1.qkv.packed_weight(r, s), bias=a1.qkv.bias_f32())
         att_o = a1.core.spatial(qkv, B, N)
         r, s = sv(a1.proj)
@@ -169,8 +173,7 @@ class PixArtMSBlock(nn.Module):
         ops.gemm_i8(ca.proj.quantize_input(att_o.view(B, N, C), s), ca.proj.packed_weight(r, s),
                     bias=ca.proj.bias_f32(), out=x2, epilogue=ops.EPI_RESID, resid=x2)
         r, s = sv(fc1)
-        qa = ops.ln_modulate_rowquant(x3, shift_mlp, scale_mlp, 1e-6, smooth=[s], n_bits=fc1.act_quantizer.n_bits,
-                                      status=st)[0]
+        qa = STDiTBlock._ln_quant(x3, shift_mlp, scale_mlp, (fc1,), [s], st)[0]
         from ..t2v.stdit import _GELU_QUANT
         one_pass = _GELU_QUANT and B == 1 and isinstance(fc2.act_quantizer, DynamicActQuantizer)   # see t2v/stdit.py
         h = ops.gemm_i8(qa, fc1.packed_weight(r, s), bias=fc1.bias_f32(), epilogue=ops.EPI_NONE if one_pass else ops.EPI_GELU)
@@ -181,14 +184,23 @@ class PixArtMSBlock(nn.Module):
         return x2
 
 
-class PixArtMS(nn.Module):
-    """PixArt-Sigma / multi-scale (PixArtMS.py:82-211); with a fixed input size it is PixArt-alpha
-    (PixArt.py:60-190: same forward with a constant positional embedding)."""
+class PixArtBlock(PixArtMSBlock):
+    """PixArt-alpha block (PixArt.py:25-57): the same adaLN-single block, called as ``block(x, y, t, mask)``."""
+
+    def forward(self, x, y, t, mask=None, **kwargs):
+        return super().forward(x, y, t, mask)
+
+
+class _PixArtBase(nn.Module):
+    """What PixArt.py:63-256 (alpha) and PixArtMS.py:82-260 (Sigma / multi-scale) share: embedders, 28 adaLN-single
+    blocks, final layer, prompt-token selection, the per-block choice between the fused HIP route and the reference
+    data flow.  Subclasses provide the positional embedding, the timestep conditioning and ``unpatchify``."""
+    block_cls = PixArtMSBlock
 
     def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
-                 mlp_ratio=4.0, class_dropout_prob=0.1, learn_sigma=True, pred_sigma=True, drop_path=0.0,
-                 caption_channels=4096, pe_interpolation=1.0, config=None, model_max_length=120,
-                 micro_condition=False, qk_norm=False, kv_compress_config=None, dtype=torch.float32, **kwargs):
+                 mlp_ratio=4.0, class_dropout_prob=0.1, pred_sigma=True, caption_channels=4096,
+                 pe_interpolation=1.0, model_max_length=120, qk_norm=False, kv_compress_config=None,
+                 dtype=torch.float32):
         super().__init__()
         self.pred_sigma = pred_sigma
         self.in_channels = in_channels
@@ -199,28 +211,26 @@ class PixArtMS(nn.Module):
         self.base_size = input_size // patch_size
         self.dtype = dtype
         self.x_embedder = PatchEmbed(patch_size, in_channels, hidden_size, bias=True)
-        # state-dict compatibility with PixArt.py:99 (MS recomputes the embedding per call; PixArt-alpha
-        # checkpoints carry it as a buffer)
-        self.register_buffer("pos_embed", torch.zeros(1, (input_size // patch_size) ** 2, hidden_size))
+        self.x_embedder.num_patches = (input_size // patch_size) ** 2
         self.t_embedder = TimestepEmbedder(hidden_size)
+        # PixArt.py:99 registers the buffer (alpha uses it; MS recomputes the embedding per call and the t2i script
+        # deletes the key from loaded checkpoints, quant_txt2img.py:232-233) - kept in both for state-dict compatibility
+        self.register_buffer("pos_embed", torch.zeros(1, self.x_embedder.num_patches, hidden_size))
         self.t_block = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
         self.y_embedder = CaptionEmbedder(in_channels=caption_channels, hidden_size=hidden_size,
                                           uncond_prob=class_dropout_prob, act_layer=approx_gelu,
                                           token_num=model_max_length)
-        self.micro_conditioning = micro_condition
-        if micro_condition:
-            self.csize_embedder = SizeEmbedder(hidden_size // 3)
-            self.ar_embedder = SizeEmbedder(hidden_size // 3)
-        if kv_compress_config is not None and kv_compress_config.get("kv_compress_layer"):
-            raise NotImplementedError("kv compression is not used by the quantized PixArt configs")
-        self.blocks = nn.ModuleList([PixArtMSBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
-        self.final_layer = T2IFinalLayer(hidden_size, patch_size * patch_size, self.out_channels)
+        if qk_norm or (kv_compress_config is not None and kv_compress_config.get("kv_compress_layer")):
+            raise NotImplementedError("kv compression / qk_norm are not used by the quantized PixArt configs")
         self.h = self.w = 0
-        self._pe_cache = {}
         self._mask_cache = None
-        self.initialize()
 
-    def initialize(self):
+    def _make_blocks(self, hidden_size, num_heads, mlp_ratio, depth, patch_size):
+        self.blocks = nn.ModuleList([self.block_cls(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
+        self.final_layer = T2IFinalLayer(hidden_size, patch_size * patch_size, self.out_channels)
+
+    def initialize_weights(self):
+        """PixArt.py:213-249 / PixArtMS.py:237-260."""
         def _basic_init(module):
             if isinstance(module, nn.Linear):
                 torch.nn.init.xavier_uniform_(module.weight)
@@ -232,6 +242,10 @@ class PixArtMS(nn.Module):
         nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
         nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
         nn.init.normal_(self.t_block[1].weight, std=0.02)
+        for emb in ("csize_embedder", "ar_embedder"):
+            if hasattr(self, emb):
+                nn.init.normal_(getattr(self, emb).mlp[0].weight, std=0.02)
+                nn.init.normal_(getattr(self, emb).mlp[2].weight, std=0.02)
         nn.init.normal_(self.y_embedder.y_proj.fc1.weight, std=0.02)
         nn.init.normal_(self.y_embedder.y_proj.fc2.weight, std=0.02)
         for block in self.blocks:
@@ -240,17 +254,8 @@ class PixArtMS(nn.Module):
         nn.init.constant_(self.final_layer.linear.weight, 0)
         nn.init.constant_(self.final_layer.linear.bias, 0)
 
-    def _pos_embed(self, device, dtype):
-        key = (self.h, self.w, str(device), dtype)
-        pe = self._pe_cache.get(key)
-        if pe is None:
-            pe = torch.from_numpy(get_2d_sincos_pos_embed(self.hidden_size, (self.h, self.w),
-                                                          pe_interpolation=self.pe_interpolation,
-                                                          base_size=self.base_size)).unsqueeze(0).to(device).to(dtype)
-            self._pe_cache[key] = pe
-        return pe
-
     def _select(self, y, mask, C):
+        """masked_select of the prompt tokens (PixArt.py:160-167); the host copy of the lengths is cached per mask."""
         B = y.shape[0]
         if mask is None:
             return y.squeeze(1).reshape(1, -1, C), [y.shape[2]] * B
@@ -262,6 +267,122 @@ class PixArtMS(nn.Module):
             self._mask_cache = (key, idx, [int(v) for v in m.sum(dim=1).tolist()], mask)   # mask kept alive
         _, idx, lens = self._mask_cache[:3]
         return y.squeeze(1).reshape(-1, C).index_select(0, idx).reshape(1, -1, C), lens
+
+    def _run_blocks(self, x, y, t0, y_lens):
+        """Every block whose Linears are all on the integer route runs fused (residual stream updated in place);
+        any other block (FP / calibration states, a running smooth-quant statistic) runs the reference data flow."""
+        bs, N, C = x.shape
+        x = x.contiguous()
+        can_fuse = x.is_cuda and x.dtype == torch.float16
+        y2 = off = t0c = None
+        for block in self.blocks:
+            if can_fuse and block.fused_ok():
+                if y2 is None:
+                    y2 = y.reshape(-1, C).contiguous()
+                    off = seq_offsets(y_lens, x.device)
+                    t0c = t0.contiguous()
+                x2 = x.reshape(bs * N, C)
+                block.forward_fused(x2, y2, t0c, off, bs)
+                x = x2.reshape(bs, N, C)
+            else:
+                x = block(x, y, t0, y_lens, HW=(self.h, self.w))
+        return x
+
+    def forward_with_cfg(self, x, timestep, y, cfg_scale, mask=None, **kwargs):
+        """PixArt.py:183-196: one batched (cond | uncond) forward, guidance on the first three channels."""
+        half = x[: len(x) // 2]
+        combined = torch.cat([half, half], dim=0)
+        model_out = self.forward(combined, timestep, y, mask, **kwargs)
+        eps, rest = model_out[:, :3], model_out[:, 3:]
+        cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
+        half_eps = uncond_eps + cfg_scale * (cond_eps - uncond_eps)
+        eps = torch.cat([half_eps, half_eps], dim=0)
+        return torch.cat([eps, rest], dim=1)
+
+
+class PixArt(_PixArtBase):
+    """PixArt-alpha (t2i/diffusion/model/nets/PixArt.py:63-256): FIXED sin-cos positional embedding held as the
+    ``pos_embed`` buffer (computed at construction for ``input_size``), no micro-conditioning embedders, square
+    ``unpatchify``.  This is the net the 256x256 configuration runs (quant_txt2img.py:226-231)."""
+    block_cls = PixArtBlock
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, class_dropout_prob=0.1, pred_sigma=True, drop_path=0.0, caption_channels=4096,
+                 pe_interpolation=1.0, config=None, model_max_length=120, qk_norm=False, kv_compress_config=None,
+                 dtype=torch.float32, **kwargs):
+        super().__init__(input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_ratio,
+                         class_dropout_prob, pred_sigma, caption_channels, pe_interpolation, model_max_length, qk_norm,
+                         kv_compress_config, dtype)
+        self._make_blocks(hidden_size, num_heads, mlp_ratio, depth, patch_size)
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        super().initialize_weights()
+        pe = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], int(self.x_embedder.num_patches ** 0.5),
+                                     pe_interpolation=self.pe_interpolation, base_size=self.base_size)
+        self.pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))      # PixArt.py:224-229
+
+    def forward(self, x, timestep, y, mask=None, data_info=None, **kwargs):
+        """PixArt.py:143-173."""
+        x = x.to(self.dtype)
+        timestep = timestep.to(self.dtype)
+        y = y.to(self.dtype)
+        C = self.hidden_size
+        self.h, self.w = x.shape[-2] // self.patch_size, x.shape[-1] // self.patch_size
+        x = self.x_embedder(x) + self.pos_embed.to(self.dtype)
+        t = self.t_embedder(timestep, dtype=x.dtype)
+        t0 = self.t_block(t)
+        y = self.y_embedder(y, self.training)
+        y, y_lens = self._select(y, mask, C)
+        x = self._run_blocks(x, y, t0, y_lens)
+        x = self.final_layer(x, t)
+        return self.unpatchify(x)
+
+    def forward_with_dpmsolver(self, x, timestep, y, mask=None, **kwargs):
+        """PixArt.py:175-181: DPM-Solver needs no variance prediction."""
+        return self.forward(x, timestep, y, mask).chunk(2, dim=1)[0]
+
+    def unpatchify(self, x):
+        """PixArt.py:198-211: square grids only (h = w = sqrt(N))."""
+        c, p = self.out_channels, self.patch_size
+        h = w = int(x.shape[1] ** 0.5)
+        assert h * w == x.shape[1]
+        x = x.reshape(x.shape[0], h, w, p, p, c)
+        x = torch.einsum("nhwpqc->nchpwq", x)
+        return x.reshape(x.shape[0], c, h * p, h * p)
+
+
+class PixArtMS(_PixArtBase):
+    """PixArt-Sigma / multi-scale (PixArtMS.py:82-260): positional embedding recomputed for the input's own
+    (h, w) grid, optional micro-conditioning (image size + aspect ratio embedders added to t, alpha at 1024)."""
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, class_dropout_prob=0.1, learn_sigma=True, pred_sigma=True, drop_path=0.0,
+                 caption_channels=4096, pe_interpolation=1.0, config=None, model_max_length=120,
+                 micro_condition=False, qk_norm=False, kv_compress_config=None, dtype=torch.float32, **kwargs):
+        super().__init__(input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_ratio,
+                         class_dropout_prob, pred_sigma, caption_channels, pe_interpolation, model_max_length, qk_norm,
+                         kv_compress_config, dtype)
+        self.micro_conditioning = micro_condition
+        if micro_condition:
+            self.csize_embedder = SizeEmbedder(hidden_size // 3)
+            self.ar_embedder = SizeEmbedder(hidden_size // 3)
+        self._make_blocks(hidden_size, num_heads, mlp_ratio, depth, patch_size)
+        self._pe_cache = {}
+        self.initialize_weights()
+
+    def initialize(self):
+        self.initialize_weights()
+
+    def _pos_embed(self, device, dtype):
+        key = (self.h, self.w, str(device), dtype)
+        pe = self._pe_cache.get(key)
+        if pe is None:
+            pe = torch.from_numpy(get_2d_sincos_pos_embed(self.hidden_size, (self.h, self.w),
+                                                          pe_interpolation=self.pe_interpolation,
+                                                          base_size=self.base_size)).unsqueeze(0).to(device).to(dtype)
+            self._pe_cache[key] = pe
+        return pe
 
     def forward(self, x, timestep, y, mask=None, data_info=None, **kwargs):
         """PixArtMS.py:165-211."""
@@ -279,19 +400,7 @@ class PixArtMS(nn.Module):
         t0 = self.t_block(t)
         y = self.y_embedder(y, self.training)
         y, y_lens = self._select(y, mask, C)
-        x = x.contiguous()
-        if x.is_cuda and x.dtype == torch.float16 and all(b.fused_ok() for b in self.blocks):
-            N = x.shape[1]
-            x2 = x.reshape(bs * N, C)
-            y2 = y.reshape(-1, C).contiguous()
-            off = seq_offsets(y_lens, x.device)
-            t0c = t0.contiguous()
-            for block in self.blocks:
-                block.forward_fused(x2, y2, t0c, off, bs)
-            x = x2.reshape(bs, N, C)
-        else:
-            for block in self.blocks:
-                x = block(x, y, t0, y_lens, (self.h, self.w))
+        x = self._run_blocks(x, y, t0, y_lens)
         x = self.final_layer(x, t)
         return self.unpatchify(x)
 
@@ -307,12 +416,11 @@ class PixArtMS(nn.Module):
         return x.reshape(x.shape[0], c, self.h * p, self.w * p)
 
 
-PixArt = PixArtMS
-
-
 def PixArtMS_XL_2(**kwargs):
+    """PixArtMS.py:268-270."""
     return PixArtMS(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)
 
 
 def PixArt_XL_2(**kwargs):
-    return PixArtMS(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)
+    """PixArt.py:313-315: the alpha net (fixed positional embedding)."""
+    return PixArt(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)

@@ -314,7 +314,31 @@ class STDiTBlock(nn.Module):
             aq = m.act_quantizer
             if not isinstance(aq, DynamicActQuantizer) and aq.per_group:
                 return False  # static per-token grids need the reference's [B, n_prompt, C] views
+            if getattr(m, "smooth_quant_running_stat", False):
+                return False  # a live act-scale statistic is QuantLayer.forward's job (host-visible state)
+        for att in (self.attn, self.attn_temp):
+            # q, k and v are quantized from ONE pass over their common input: that needs one activation bit-width
+            # and one kind of quantizer (a mixed-precision YAML may set them apart: then the layerwise route runs)
+            aqs = [l.act_quantizer for l in (att.q, att.k, att.v)]
+            if len({(a.n_bits, isinstance(a, DynamicActQuantizer)) for a in aqs}) != 1:
+                return False
         return True
+
+    @staticmethod
+    def _ln_quant(x3, shift, scale, layers, svs, status):
+        """LayerNorm + modulate + the activation quantizer(s) of ``layers`` (which share the input).  Dynamic
+        per-token quantizers: ONE fused kernel, one output per distinct smoothing vector.  Static calibrated grids
+        (``dynamic: False``, the *_naive / *_ptqd plans): the fused kernel computes min-max grids only, so it emits the
+        modulated fp16 activation and every layer quantizes it on ITS calibrated (delta, zero_point)
+        (base_quantizer.py:129-144) - never a silently substituted dynamic grid."""
+        l0 = layers[0]
+        if all(isinstance(l.act_quantizer, DynamicActQuantizer) for l in layers):
+            smooth = [None] if all(s is None for s in svs) else list(svs)
+            return ops.ln_modulate_rowquant(x3, shift, scale, 1e-6, smooth=smooth, n_bits=l0.act_quantizer.n_bits,
+                                            status=status)
+        _, xm = ops.ln_modulate_rowquant(x3, shift, scale, 1e-6, smooth=[None], n_bits=8, want_xm=True)
+        # one pass per layer: each has its own calibrated grid tensor (comparing them would be a host sync)
+        return [l.quantize_input(xm, s) for l, s in zip(layers, svs)]
 
     def forward(self, x, y, t, mask=None, tpe=None):
         if x.is_cuda and x.dtype == torch.float16 and self.fused_ok():
@@ -419,9 +443,7 @@ class STDiTBlock(nn.Module):
 
         # ---- spatial branch: x += gate_msa * proj(attn(LN-mod(x)))          (stdit.py:103-109)
         svs = [svec(l) for l in (a1.q, a1.k, a1.v)]
-        smooth = [None] if all(s is None for s in svs) else svs
-        qas = ops.ln_modulate_rowquant(x3, shift_msa, scale_msa, 1e-6, smooth=smooth,
-                                       n_bits=a1.q.act_quantizer.n_bits, status=st)
+        qas = self._ln_quant(x3, shift_msa, scale_msa, (a1.q, a1.k, a1.v), svs, st)
         qkv = qkv_proj(a1, qas)
         att_o = a1.core.spatial(qkv, B * T, S)
         qa = a1.proj.quantize_input(att_o.view(B, N, C), svec(a1.proj))
@@ -431,7 +453,7 @@ class STDiTBlock(nn.Module):
         # ---- temporal branch on the un-modulated x (+tpe in block 0)          (stdit.py:112-118)
         svs = [svec(l) for l in (a2.q, a2.k, a2.v)]
         tpe2 = None if tpe is None else tpe.reshape(T, C).contiguous()
-        if all(s is None for s in svs):
+        if all(s is None for s in svs) and isinstance(a2.q.act_quantizer, DynamicActQuantizer):
             qas = [a2.q.quantize_input(x3, None, add_rows=tpe2, add_div=S)]
         else:
             qas = [l.quantize_input(x3, s, add_rows=tpe2, add_div=S) for l, s in zip((a2.q, a2.k, a2.v), svs)]
@@ -457,8 +479,7 @@ class STDiTBlock(nn.Module):
 
         # ---- MLP: x += gate_mlp * fc2(gelu(fc1(LN-mod(x))))                   (stdit.py:124-128)
         fc1, fc2 = self.mlp.fc1, self.mlp.fc2
-        qa = ops.ln_modulate_rowquant(x3, shift_mlp, scale_mlp, 1e-6, smooth=[svec(fc1)],
-                                      n_bits=fc1.act_quantizer.n_bits, status=st)[0]
+        qa = self._ln_quant(x3, shift_mlp, scale_mlp, (fc1,), [svec(fc1)], st)[0]
         one_pass = B == 1 and isinstance(fc2.act_quantizer, DynamicActQuantizer) and _GELU_QUANT
         h = ops.gemm_i8(qa, fc1.packed_weight(r, svec(fc1)), bias=fc1.bias_f32(),
                         epilogue=ops.EPI_NONE if one_pass else ops.EPI_GELU)
