@@ -2,8 +2,11 @@
 
 TEST INFRASTRUCTURE ONLY.  Follows t2i/diffusion/model/nets/PixArtMS.py:71-79 (block), :165-211
 (model), PixArt_blocks.py:125-160 (fused-qkv self attention) and :43-60 (cross attention); quantized
-Linears as qdiff/models/dit_quant_layer.py:14-79 (no smooth-quant branch).  Pinned on a golden
-produced by the imported reference (tests/golden/make_golden.py::tiny_pixart).
+Linears as qdiff/models/dit_quant_layer.py:14-79 (no smooth-quant branch; the mlp Linears are plain
+QuantLayers and DO have one - QSpec.act_scale / running_stat).  The alpha net (PixArt.py:143-173) is the same
+forward with ``pos_embed`` = the model's fixed buffer (``sd['pos_embed']``) and no micro-conditioning.
+Pinned on goldens produced by the imported reference (tests/golden/make_golden.py::tiny_pixart,
+::tiny_pixart_alpha, ::tiny_pixart_w4a8).
 """
 from __future__ import annotations
 
@@ -31,9 +34,12 @@ def pixart_block(sd, i, x, y, t0, y_lens, H, spec: QSpec, t_id=0):
     return x + gate_mlp * qlinear(sd, p + ".mlp.fc2", fq.gelu_tanh(h), spec, t_id)
 
 
-def pixart_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, pos_embed: torch.Tensor):
-    """cfg: dict(H, depth, patch, out_ch).  ``pos_embed`` [1, N, C] as the model computes it."""
+def pixart_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, pos_embed: torch.Tensor, t_id=None):
+    """cfg: dict(H, depth, patch, out_ch).  ``pos_embed`` [1, N, C] as the model computes it (MS) or holds it
+    (alpha: sd['pos_embed']).  ``t_id``: QuantModel pushes timestep[0] to every layer (quant_model.py:347)."""
     H, depth, p_ = cfg["H"], cfg["depth"], cfg["patch"]
+    if t_id is None:
+        t_id = int(timestep[0])
     x = F.conv2d(x.float(), sd["x_embedder.proj.weight"].float(), sd["x_embedder.proj.bias"].float(), stride=p_)
     hh, ww = x.shape[-2:]
     x = x.flatten(2).transpose(1, 2) + pos_embed.float()
@@ -53,9 +59,9 @@ def pixart_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, pos_embed: 
         y_lens = [yy.shape[2]] * yy.shape[0]
         yy = yy.squeeze(1).reshape(1, -1, C)
     for i in range(depth):
-        x = pixart_block(sd, i, x, yy, t0, y_lens, H, spec)
+        x = pixart_block(sd, i, x, yy, t0, y_lens, H, spec, t_id)
     shift, scale = (sd["final_layer.scale_shift_table"].float()[None] + t[:, None]).chunk(2, dim=1)
-    xf = qlinear(sd, "final_layer.linear", fq.t2i_modulate(fq.layernorm_noaffine(x), shift, scale), spec)
+    xf = qlinear(sd, "final_layer.linear", fq.t2i_modulate(fq.layernorm_noaffine(x), shift, scale), spec, t_id)
     c = cfg["out_ch"]
     xf = xf.reshape(B, hh, ww, p_, p_, c)
     return torch.einsum("nhwpqc->nchpwq", xf).reshape(B, c, hh * p_, ww * p_)

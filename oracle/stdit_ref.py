@@ -37,6 +37,17 @@ class QSpec:
     smooth_off: Sequence[str] = ("x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer")
     # weight grids fixed at PTQ: name -> (delta [N,1], zp [N,1]); filled lazily when absent
     w_grid: Dict[str, tuple] = field(default_factory=dict)
+    # activation quantizers: 'dynamic' (per token, online) or 'static' = calibrated grids a_grid[name] = (delta, zp),
+    # tensor-wise (a_per_group False, scalars) or per token (a_per_group 'token', [1, n_tok, 1])
+    # (base_quantizer.py:129-144 after init_done; configs w8a8_naive / *_ptqd)
+    act_mode: str = "dynamic"
+    a_per_group: object = "token"
+    a_grid: Dict[str, tuple] = field(default_factory=dict)
+    n_prompt: int = 0
+    # layers whose smooth-quant act-scale statistic keeps running at inference (quant_layer.py:118-126; the t2i
+    # scripts leave it on for the last block's mlp.fc2): updated in place in ``act_scale`` on every call
+    running_stat: Sequence[str] = ()
+    momentum: float = 0.95
 
 
 def _is_fp(name: str, spec: QSpec) -> bool:
@@ -62,10 +73,28 @@ def qlinear(sd, name: str, x3: torch.Tensor, spec: QSpec, t_id: int = 0) -> torc
                 W = W * sm
         return F.linear(xf, W, b)
     smooth = None
+    if name in spec.running_stat:
+        # momentum statistic of max|x| per input channel, updated BEFORE s is derived (quant_layer.py:118-126)
+        r = fq.find_interval(spec.timerange, t_id)
+        cur = fq.act_scale_stat(x3)
+        if name not in spec.act_scale:
+            spec.act_scale[name] = torch.zeros([len(spec.timerange)] + list(cur.shape))
+        a = spec.act_scale[name]
+        a[r] = cur if float(a[r].abs().mean()) == 0 else a[r] * spec.momentum + cur * (1 - spec.momentum)
     if name in spec.act_scale and spec.alpha is not None:
         r = fq.find_interval(spec.timerange, t_id)
         alpha = spec.alpha[r] if isinstance(spec.alpha, (list, tuple)) else spec.alpha
         smooth = fq.smooth_scale(spec.act_scale[name][r], W, alpha)
+    if spec.act_mode == "static":
+        wd, wz = spec.w_grid[name] if name in spec.w_grid else fq.weight_params(W, spec.w_bits)
+        spec.w_grid[name] = (wd, wz)
+        ad, az = spec.a_grid[name]
+        xq = x3
+        if spec.a_per_group == "token" and name.endswith("kv_linear") and x3.shape[0] == 1 and spec.n_prompt:
+            xq = x3.reshape(-1, spec.n_prompt, x3.shape[-1])          # stdit_quant_layer.py:272-278
+        out = fq.quant_linear(xq, W, b, w_bits=spec.layer_w_bits.get(name, spec.w_bits), a_bits=spec.a_bits,
+                              w_delta=wd, w_zp=wz, smooth=smooth, act_mode="static", a_delta=ad, a_zp=az)
+        return out.reshape(*x3.shape[:-1], out.shape[-1])
     if name not in spec.w_grid:
         W0 = W
         if name in spec.act_scale and spec.alpha is not None:
@@ -143,8 +172,9 @@ def timestep_embedding(t, dim=256, max_period=10000):
 
 def stdit_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, t_id: Optional[int] = None,
                   return_blocks: bool = False):
-    """STDiT.forward (stdit.py:238-341) with dynamic act quant => MASK_SELECT=True.
-    cfg: dict(T,S,H,depth,patch,in_ch,out_ch,input_size)."""
+    """STDiT.forward (stdit.py:238-341).  Prompt tokens: masked_select (MASK_SELECT True) unless the activation
+    quantizers are static AND per token - then the padding tokens are zeroed and every sample keeps all n_prompt
+    rows (stdit.py:272-301).  cfg: dict(T,S,H,depth,patch,in_ch,out_ch,input_size)."""
     T, S, H, depth = cfg["T"], cfg["S"], cfg["H"], cfg["depth"]
     if t_id is None:
         t_id = int(timestep[0])
@@ -161,10 +191,15 @@ def stdit_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, t_id: Option
     yy = F.linear(fq.gelu_tanh(F.linear(y.float(), sd["y_embedder.y_proj.fc1.weight"].float(),
                                         sd["y_embedder.y_proj.fc1.bias"].float())),
                   sd["y_embedder.y_proj.fc2.weight"].float(), sd["y_embedder.y_proj.fc2.bias"].float())
-    if mask is not None:
+    mask_select = not (spec.quant and spec.act_mode == "static" and spec.a_per_group == "token")
+    if mask is not None and mask_select:
         m = mask if mask.shape[0] == yy.shape[0] else mask.repeat(yy.shape[0] // mask.shape[0], 1)
         y_lens = [int(v) for v in m.sum(dim=1).tolist()]
         yy = yy.squeeze(1).masked_select(m.unsqueeze(-1) != 0).view(1, -1, C)
+    elif mask is not None:
+        m = mask if mask.shape[0] == yy.shape[0] else mask.repeat(2, 1)
+        y_lens = [yy.shape[2]] * yy.shape[0]
+        yy = (yy * m.unsqueeze(-1).unsqueeze(1)).squeeze(1).reshape(1, -1, C)
     else:
         y_lens = [yy.shape[2]] * yy.shape[0]
         yy = yy.squeeze(1).reshape(1, -1, C)

@@ -28,6 +28,9 @@ def h(t):
     return t.half().float()
 
 
+OUT_DIR = os.environ.get("GOLDEN_OUT", HERE)      # GOLDEN_OUT=/tmp/x: regenerate elsewhere (reproducibility check)
+
+
 def npz(name, **arrs):
     out = {}
     for k, v in arrs.items():
@@ -36,7 +39,7 @@ def npz(name, **arrs):
         if getattr(v, "dtype", None) == np.float32 and np.array_equal(v.astype(np.float16).astype(np.float32), v):
             v = v.astype(np.float16)   # exactly representable: store compactly (loaders upcast)
         out[k] = v
-    np.savez_compressed(os.path.join(HERE, name), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, name), **out)
     print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
@@ -198,8 +201,44 @@ def wrap(R, m, w_bits, smooth=None, mixed_precision=None):
     return qnn
 
 
+def _ks_file(tmp, ks):
+    os.makedirs(os.path.join(tmp, "t2v", "rebuttal_files"))
+    torch.save(ks, os.path.join(tmp, "t2v", "rebuttal_files", "k_for_each_timestep.pth"))
+
+
+def _ddim(qnn, steps, z, y, mask, ks=None, n_dup=2):
+    """The reference's own DDIM loop around forward_with_cfg (PTQD table ``ks`` placed where it loads it from)."""
+    from functools import partial
+    from opensora.schedulers.iddpm import IDDPM, forward_with_cfg  # noqa
+    tmp = tempfile.mkdtemp()
+    _ks_file(tmp, torch.zeros(20) if ks is None else ks)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        sch = IDDPM(num_sampling_steps=steps, cfg_scale=4.0)
+        samples = sch.ddim_sample_loop(partial(forward_with_cfg, qnn, cfg_scale=4.0), (2,) + tuple(z.shape[1:]),
+                                       torch.cat([z, z]), clip_denoised=False, model_kwargs=dict(y=y, mask=mask),
+                                       progress=False, device="cpu")
+    finally:
+        os.chdir(cwd)
+    return samples[:1], sch
+
+
+def _half_copy(qnn):
+    """The reference in ITS fp16 mode (model and quant buffers .half(), as every script runs it on a GPU), on CPU
+    half kernels: the yardstick for what 'fp16 storage between layers' does to the fp32 result."""
+    import copy
+    q16 = copy.deepcopy(qnn).half()
+    try:
+        q16.model.dtype = torch.float16       # STDiT keeps it as an attribute; the PixArt nets derive it from parameters
+    except AttributeError:
+        pass
+    return q16
+
+
 def tiny_stdit(R):
     out = {}
+    ref16 = {}                     # -> tiny_stdit_fp16ref.npz
     m = build_tiny(R)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     for k, v in sd.items():
@@ -234,6 +273,19 @@ def tiny_stdit(R):
         q16 = copy.deepcopy(qnn).half()
         q16.model.dtype = torch.float16
         out["w8a8_cond_ref_fp16"] = q16(x, t, y[:1].half(), mask=mask).float()
+        # (second file) every block output and the other forwards in the reference's fp16 mode
+        blocks16 = []
+        hooks = [b.register_forward_hook(lambda mod, i, o: blocks16.append(o.clone())) for b in q16.model.blocks]
+        ref16["w8a8_cond_ref_fp16"] = q16(x, t, y[:1].half(), mask=mask).float()
+        for hk in hooks:
+            hk.remove()
+        for i, b in enumerate(blocks16):
+            ref16["w8a8_block%d_ref_fp16" % i] = b.float()
+        ref16["w8a8_uncond_ref_fp16"] = q16(x, t, y[1:].half(), mask=mask).float()
+        ref16["w8a8_joint_ref_fp16"] = q16(torch.cat([x, x]), torch.cat([t, t]), y.half(), mask=mask).float()
+        q16.cfg_split = True
+        z16 = h(torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(42)))
+        ref16["ddim_final_ref_fp16"] = _ddim(q16, 3, z16, y.half(), mask)[0].float()
         q16.set_quant_state(False, False)
         out["fp_cond_ref_fp16"] = q16(x, t, y[:1].half(), mask=mask).float()
         del q16
@@ -301,9 +353,16 @@ def tiny_stdit(R):
         out["x"], out["y"], out["mask"] = x, y, mask
         for tv in (721, 300):
             out["w4a8_cond_t%d" % tv] = qnn(x, torch.tensor([tv]), y[:1], mask=mask)
+        q16 = _half_copy(qnn)
+        for tv in (721, 300):
+            ref16["w4a8_cond_t%d_ref_fp16" % tv] = q16(x, torch.tensor([tv]), y[:1].half(), mask=mask).float()
+        del q16
         # mixed precision: one layer switched to 8 bit (wider clamp on the 4-bit grid)
         qnn.load_bitwidth_config(qnn, {"model.blocks.0.mlp.fc1": 8, "model.blocks.1.attn.q": 8}, "weight")
         out["w4a8_mp_cond_t721"] = qnn(x, torch.tensor([721]), y[:1], mask=mask)
+        q16 = _half_copy(qnn)
+        ref16["w4a8_mp_cond_t721_ref_fp16"] = q16(x, torch.tensor([721]), y[:1].half(), mask=mask).float()
+        del q16
         qd = qnn.get_quant_params_dict()
         for name, (bufs, params) in qd.items():
             for bn, bv in bufs.items():
@@ -340,9 +399,21 @@ def tiny_stdit(R):
                 progress=False, device="cpu")
             out["mp_ddim_final"] = samples[:1]
             out["mp_ddim_timestep_map"] = np.array(sch.timestep_map)
+            # the same loop with the reference in its fp16 mode (fresh switching state: restore the 4-bit base first)
+            qnn.load_bitwidth_config(qnn, {n: 4 for n in names}, "weight")
+            qnn.set_quant_state(True, True)
+            q16 = _half_copy(qnn)
+            q16.timestep_wise_mp, q16.time_mp_config_weight, q16.time_mp_config_act = True, wcfg, acfg
+            s16 = sch.ddim_sample_loop(
+                partial(forward_with_cfg, q16, cfg_scale=4.0),
+                (2, 4, 4, 8, 8), torch.cat([z, z]), clip_denoised=False, model_kwargs=dict(y=yy.half(), mask=mask),
+                progress=False, device="cpu")
+            ref16["mp_ddim_final_ref_fp16"] = s16[:1].float()
+            del q16
         finally:
             os.chdir(cwd)
     npz("tiny_stdit_w4a8.npz", **out)
+    npz("tiny_stdit_fp16ref.npz", **ref16)
 
 
 # ----------------------------------------------------------------------------- 4. tiny PixArtMS
@@ -405,16 +476,233 @@ def tiny_pixart():
     npz("tiny_pixart_w8a8.npz", **out)
 
 
+# ----------------------------------------------------------------------------- 3b. static activation plans (A3)
+def _qp(out, prefix, qnn):
+    qd = qnn.get_quant_params_dict()
+    for name, (bufs, params) in qd.items():
+        for bn, bv in bufs.items():
+            if bv is not None:
+                out["%s/%s/%s" % (prefix, name, bn)] = bv.clone()    # a snapshot: running statistics move in place
+
+
+def tiny_stdit_static(R):
+    """The *_naive / *_ptqd plans of t2v/configs/quant/opensora (``per_group: False, dynamic: False``: one calibrated
+    (delta, zero_point) per activation tensor; cfg_split False), calibrated by the passes of t2v/scripts/ptq.py:266-362
+    on a stored calibration set; the PTQD division (iddpm/__init__.py:168-172) with a non-zero table; and the
+    static PER-TOKEN variant, which switches STDiT.forward to its zero-mask prompt path (stdit.py:272-301,
+    MASK_SELECT False) and the kv_linear [B, n_prompt, C] view (stdit_quant_layer.py:272-278)."""
+    out = {}
+    m = build_tiny(R, seed=30)
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.clone()
+    fp = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+    # calibration set in the layout get_quant_calib_data returns (qdiff/utils.py:20-63): per step 2n rows (x dup,
+    # y = cond | uncond, mask repeated), three steps, n = 1, batch size 2
+    ins = [tiny_inputs(1, seed=60 + i) for i in range(3)]
+    xs = torch.cat([torch.cat([a[0], a[0]]) for a in ins])
+    cs = torch.cat([a[1] for a in ins])
+    ms = torch.cat([a[2].repeat(2, 1) for a in ins])
+    ts = torch.tensor([900, 900, 500, 500, 100, 100])
+    out["calib_xs"], out["calib_ts"], out["calib_cs"], out["calib_masks"] = xs, ts, cs, ms
+    x, y, mask = tiny_inputs(1, seed=70)
+    out["x"], out["y"], out["mask"] = x, y, mask
+    ks = torch.linspace(0.02, 0.4, 20)
+    out["ks"] = ks
+    z = h(torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(44)))
+    out["ddim_z"] = z
+    for tag, per_group in (("tw", False), ("tk", "token")):
+        import copy
+        wq = ref_import.wq_cfg(8, mixed_precision=[4, 6, 8])
+        aq = ref_import.aq_cfg(dynamic=False, per_group=per_group, T=4, S=16, n_prompt=12)
+        with torch.no_grad():
+            qnn = R.QuantModel(copy.deepcopy(m), wq, aq)
+            qnn.set_module_name_for_quantizer(qnn.model)
+            qnn.cfg_split = False
+            bs = 2
+            tmp_mask = ms[:bs][::2]
+            # weight grids (ptq.py:266-293, part_fp)
+            qnn.set_quant_state(True, False)
+            qnn.set_layer_quant(model=qnn, module_name_list=fp, quant_level="per_layer", weight_quant=False,
+                                act_quant=False, prefix="")
+            qnn(xs[:bs], ts[:bs], cs[:bs], mask=tmp_mask)
+            qnn.set_quant_init_done("weight")
+            # activation grids: every batch re-initialises them, the last one stays (:296-318, running_stat False)
+            qnn.set_quant_state(True, True)
+            qnn.set_layer_quant(model=qnn, module_name_list=fp, quant_level="per_layer", weight_quant=False,
+                                act_quant=False, prefix="")
+            for i in range(xs.shape[0] // bs):
+                sl = slice(i * bs, (i + 1) * bs)
+                qnn(xs[sl], ts[sl], cs[sl], mask=ms[sl][::2])
+            qnn.set_quant_init_done("activation")
+            _qp(out, "qp_" + tag, qnn)
+            t = torch.tensor([721, 721])
+            out[tag + "_joint_t721"] = qnn(torch.cat([x, x]), t, y, mask=mask)
+            out[tag + "_cond_t300"] = qnn(x, torch.tensor([300]), y[:1], mask=mask)
+            q16 = _half_copy(qnn)
+            out[tag + "_joint_t721_ref_fp16"] = q16(torch.cat([x, x]), t, y.half(), mask=mask).float()
+            if tag == "tw":    # PTQD: 3 guided DDIM steps, every model output divided by 1 + ks[(999 - t) // 50]
+                fin, sch = _ddim(qnn, 3, z, y, mask, ks=ks)
+                out["tw_ptqd_ddim_final"] = fin
+                out["tw_ptqd_timestep_map"] = np.array(sch.timestep_map)
+                out["tw_ptqd_ddim_final_ref_fp16"] = _ddim(q16, 3, z, y.half(), mask, ks=ks)[0].float()
+            del q16
+    npz("tiny_stdit_static.npz", **out)
+
+
+# ----------------------------------------------------------------------------- 4b. PixArt-alpha and PixArt W4A8
+def _tiny_pixart_net(cls, seed):
+    torch.manual_seed(seed)
+    m = cls(input_size=16, depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if p_.abs().sum() == 0:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
+        for p_ in m.parameters():
+            p_.copy_(h(p_))
+        for n, b_ in m.named_buffers():
+            b_.copy_(h(b_))
+    m.eval()
+    return m, g
+
+
+PIX_FP = ["x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder"]
+
+
+def _pixart_ptq(R, m, wq, aq, x, t, y, mask, smooth_layers=None, calib=None):
+    """t2i/scripts/ptq.py:218-318 in its own order: (smooth-quant flags for the listed layers), FP forward, weight
+    forward, FP layer list, static activation batches unless dynamic."""
+    qnn = R.QuantModel(m, wq, aq, model_type="pixart")
+    if smooth_layers is not None:
+        qnn.set_smooth_quant(smooth_quant=False, smooth_quant_running_stat=False)
+        qnn.set_layer_smooth_quant(model=qnn, module_name_list=smooth_layers, smooth_quant=True,
+                                   smooth_quant_running_stat=True)
+    qnn(x, t, y, mask=mask)
+    qnn.set_module_name_for_quantizer(qnn.model)
+    qnn.set_quant_state(True, False)
+    qnn(x, t, y, mask=mask)
+    qnn.set_quant_init_done("weight")
+    qnn.set_quant_state(True, True)
+    qnn.fp_layer_list = list(PIX_FP)
+    qnn.set_layer_quant(model=qnn, module_name_list=PIX_FP, quant_level="per_layer", weight_quant=False,
+                        act_quant=False, prefix="")
+    if calib is not None:
+        for (cx, ct, cy, cm) in calib:
+            qnn(cx, ct, cy, mask=cm)
+    qnn.set_quant_init_done("activation")
+    return qnn
+
+
+def tiny_pixart_alpha():
+    """BASELINE config 1: the PixArt-ALPHA net (PixArt.py:63-256: fixed pos_embed buffer, PixArtBlock, no
+    micro-conditioning) at a 16x16 latent (N = 64), W8A8 dynamic per token and the static tensor-wise 'naive' plan."""
+    R = ref_import.load_t2i()
+    import importlib
+    PixArt = importlib.import_module("diffusion.model.nets.PixArt").PixArt
+    out = {}
+    m, g = _tiny_pixart_net(PixArt, 13)
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.clone()
+    x = h(torch.randn(2, 4, 16, 16, generator=g))
+    y = h(torch.randn(2, 1, 12, 32, generator=g) * 0.5)
+    mask = torch.zeros(2, 12, dtype=torch.int64)
+    mask[0, :5] = 1
+    mask[1, :11] = 1
+    t = torch.tensor([640, 640])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    import copy
+    with torch.no_grad():
+        out["fp"] = m(x, t.float(), y, mask=mask)
+        qnn = _pixart_ptq(R, copy.deepcopy(m), ref_import.wq_cfg(8), ref_import.aq_cfg(T=1, S=64, n_prompt=12),
+                          x, t, y, mask)
+        assert type(qnn.model.blocks[0]).__name__ == "PixArtBlock"
+        out["w8a8"] = qnn(x, t, y, mask=mask)
+        out["w8a8_b1"] = qnn(x[:1], t[:1], y[:1], mask=mask[:1])       # the single-prompt configuration
+        q16 = _half_copy(qnn)
+        out["w8a8_b1_ref_fp16"] = q16(x[:1], t[:1], y[:1].half(), mask=mask[:1]).float()
+        del q16
+        _qp(out, "qp", qnn)
+        # static tensor-wise plan (alpha/w8a8_naive.yaml): two calibration batches, the last one stays
+        g2 = torch.Generator().manual_seed(131)
+        calib = [(h(torch.randn(2, 4, 16, 16, generator=g2)), torch.tensor([tt, tt]),
+                  h(torch.randn(2, 1, 12, 32, generator=g2) * 0.5), mask) for tt in (900, 200)]
+        for j, (cx, ct, cy, cm) in enumerate(calib):
+            out["calib%d_x" % j], out["calib%d_t" % j], out["calib%d_y" % j] = cx, ct, cy
+        qn = _pixart_ptq(R, copy.deepcopy(m), ref_import.wq_cfg(8),
+                         ref_import.aq_cfg(dynamic=False, per_group=False, T=1, S=64, n_prompt=12),
+                         calib[0][0], calib[0][1], calib[0][2], calib[0][3], calib=calib)
+        out["naive"] = qn(x, t, y, mask=mask)
+        _qp(out, "qp_naive", qn)
+        # DPM-Solver++ 2M, 4 guided steps, through the alpha entry point (quant_txt2img.py:133-138)
+        dps = importlib.import_module("diffusion.dpm_solver_alpha")
+        z = h(torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(87)))
+        null_y = h(torch.randn(1, 1, 12, 32, generator=torch.Generator().manual_seed(88)) * 0.5)
+        solver = dps.DPMS_alpha(qnn.forward_with_dpmsolver, condition=y[:1], uncondition=null_y, cfg_scale=4.5,
+                                model_kwargs=dict(data_info=None, mask=mask[:1]))
+        out["dpm_z"], out["dpm_null_y"] = z, null_y
+        out["dpm_final"] = solver.sample(z, steps=4, order=2, skip_type="time_uniform", method="multistep")
+    npz("tiny_pixart_alpha.npz", **out)
+
+
+def tiny_pixart_w4a8():
+    """BASELINE config 5 in miniature: PixArt-MS with 4-bit weights (grids for [4,6,8]), dynamic per-token 8-bit
+    activations, and the t2i script's smooth-quant arrangement - channel balancing (alpha 0.3, momentum statistic)
+    on the LAST block's mlp.fc2 only, with its running statistic left on at inference (ptq.py:222-226,
+    quant_txt2img.py:297-300): every forward moves act_scale and therefore s, W*s and the outputs."""
+    R = ref_import.load_t2i()
+    out = {}
+    m, g = _tiny_pixart_net(R.PixArtMS, 23)
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.clone()
+    x = h(torch.randn(2, 4, 16, 16, generator=g))
+    y = h(torch.randn(2, 1, 12, 32, generator=g) * 0.5)
+    mask = torch.zeros(2, 12, dtype=torch.int64)
+    mask[0, :8] = 1
+    mask[1, :12] = 1
+    t = torch.tensor([820, 820])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    smooth = dict(alpha=0.3)
+    with torch.no_grad():
+        qnn = _pixart_ptq(R, m, ref_import.wq_cfg(4, mixed_precision=[4, 6, 8]),
+                          ref_import.aq_cfg(T=1, S=64, n_prompt=12, smooth=smooth), x, t, y, mask,
+                          smooth_layers=["blocks.1.mlp.fc2"])
+        _qp(out, "qp_after_ptq", qnn)
+        # inference state of quant_txt2img.py:288-303 (same flags; the statistic keeps running)
+        outs = []
+        for j, tv in enumerate((820, 400, 90)):
+            tt = torch.tensor([tv, tv])
+            outs.append(qnn(x, tt, y, mask=mask))
+            out["w4a8_call%d_t%d" % (j, tv)] = outs[-1]
+            out["act_scale_after_call%d" % j] = qnn.model.blocks[1].mlp.fc2.act_quantizer.act_scale.clone()
+        # mixed precision on top: qkv of block 0 at 8 bit, fc1 of block 1 at 6 (wider clamp, 4-bit grid)
+        qnn.load_bitwidth_config(qnn, {"model.blocks.0.attn.qkv": 8, "model.blocks.1.mlp.fc1": 6}, "weight")
+        out["w4a8_mp_call3_t820"] = qnn(x, t, y, mask=mask)
+        out["act_scale_after_call3"] = qnn.model.blocks[1].mlp.fc2.act_quantizer.act_scale.clone()
+        _qp(out, "qp", qnn)
+    npz("tiny_pixart_w4a8.npz", **out)
+
+
 def main():
     assert ref_import.available(), "needs /root/reference"
     torch.set_grad_enabled(False)
+    only = [a[7:] for a in sys.argv if a.startswith("--only=")]
+    want = lambda name: (not only) or name in only   # noqa: E731
     if "--pixart-only" not in sys.argv:
         R = ref_import.load()
-        quantizer_kats(R)
-        layer_kats(R)
-        tiny_stdit(R)
+        if want("kats"):
+            quantizer_kats(R)
+            layer_kats(R)
+        if want("stdit"):
+            tiny_stdit(R)
+        if want("static"):
+            tiny_stdit_static(R)
     if "--stdit-only" not in sys.argv:
-        tiny_pixart()
+        if want("pixart"):
+            tiny_pixart()
+        if want("alpha"):
+            tiny_pixart_alpha()
+        if want("pixart_w4a8"):
+            tiny_pixart_w4a8()
 
 
 if __name__ == "__main__":

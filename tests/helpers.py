@@ -25,13 +25,23 @@ def state_dict_of(gold):
     return {k[3:]: v for k, v in gold.items() if k.startswith("sd/")}
 
 
-def quant_params_of(gold):
-    """{module_name: {buffer_name: tensor}} from the flattened ckpt.pth-schema arrays."""
+def quant_params_of(gold, prefix="qp"):
+    """{module_name: {buffer_name: tensor}} from the flattened ckpt.pth-schema arrays ``<prefix>/<module>/<buffer>``."""
     out = {}
     for k, v in gold.items():
-        if k.startswith("qp/"):
+        if k.startswith(prefix + "/"):
             _, name, buf = k.split("/")
             out.setdefault(name, {})[buf] = v
+    return out
+
+
+def grids_of(qp, kind):
+    """{layer: (delta, zero_point)} of every ``<layer>.<kind>`` quantizer (kind: weight_quantizer | act_quantizer)
+    that holds a calibrated grid."""
+    out = {}
+    for name, bufs in qp.items():
+        if name.endswith("." + kind) and bufs.get("delta") is not None:
+            out[name[:-len(kind) - 1]] = (bufs["delta"], bufs["zero_point"])
     return out
 
 

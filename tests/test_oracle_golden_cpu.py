@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import TINY_CFG, load_npz, quant_params_of, rel_l2, state_dict_of
+from helpers import TINY_CFG, grids_of, load_npz, quant_params_of, rel_l2, state_dict_of
 from oracle import fakequant as fq
 from oracle import stdit_ref as sr
 
@@ -171,6 +171,82 @@ def test_tiny_pixart_w8a8():
     assert rel_l2(out[:1], out1) > 1e-4                         # batch-shared token scales change the result
 
 
+@pytest.mark.parametrize("tag,per_group", [("tw", False), ("tk", "token")])
+def test_tiny_stdit_static_activation_plans(tag, per_group):
+    """w8a8_naive / *_ptqd (tensor-wise calibrated activation grids, cfg_split False) and the static per-token
+    variant with its zero-mask prompt path (stdit.py:272-301) and [B, n_prompt, C] kv view; PTQD division with a
+    non-zero table through 3 guided DDIM steps."""
+    g = load_npz("tiny_stdit_static.npz")
+    sd = state_dict_of(g)
+    qp = quant_params_of(g, "qp_" + tag)
+    wg = {n: (d.reshape(-1, 1), z.reshape(-1, 1)) for n, (d, z) in grids_of(qp, "weight_quantizer").items()}
+    ag = grids_of(qp, "act_quantizer")
+    if per_group == "token":      # the zeroed padding tokens force the global eps fill on kv_linear (base_quantizer.py:220-222)
+        assert torch.all(ag["blocks.0.cross_attn.kv_linear"][0] == 1e-6)
+    spec = sr.QSpec(w_bits=8, act_mode="static", a_per_group=per_group, a_grid=ag, w_grid=wg, n_prompt=12)
+    x, y, mask = g["x"], g["y"], g["mask"]
+    t = torch.tensor([721, 721])
+    joint = sr.stdit_forward(sd, TINY_CFG, torch.cat([x, x]), t, y, mask, spec)
+    assert rel_l2(joint, g[tag + "_joint_t721"]) < 1e-5
+    cond = sr.stdit_forward(sd, TINY_CFG, x, torch.tensor([300]), y[:1], mask, spec)
+    assert rel_l2(cond, g[tag + "_cond_t300"]) < 1e-5
+    if tag == "tw":
+        tmap, acp = sr.spaced_schedule(3)
+        assert tmap == [int(v) for v in g["tw_ptqd_timestep_map"]]
+        xx = g["ddim_z"]
+        for i in (2, 1, 0):
+            tt = torch.tensor([tmap[i], tmap[i]])
+            out = sr.stdit_forward(sd, TINY_CFG, torch.cat([xx, xx]), tt, y, mask, spec)   # cfg_split False
+            k = float(g["ks"][(999 - tmap[i]) // 50])
+            xx = sr.cfg_ddim_step(xx, out[:1], out[1:], acp, i, 4.0, k=k)
+        assert rel_l2(xx, g["tw_ptqd_ddim_final"]) < 1e-4
+
+
+def test_tiny_pixart_alpha_net():
+    """BASELINE config 1: the alpha net (fixed pos_embed buffer, PixArtBlock): FP, W8A8 dynamic (B = 2 shared
+    token scales and the single-prompt B = 1 case), and the static tensor-wise 'naive' plan."""
+    from oracle import pixart_ref as pr
+    g = load_npz("tiny_pixart_alpha.npz")
+    sd = state_dict_of(g)
+    cfg = dict(H=4, depth=2, patch=2, out_ch=8)
+    x, y, mask, t = g["x"], g["y"], g["mask"], g["t"]
+    pe = sd["pos_embed"]
+    assert pe.abs().sum() > 0                                  # alpha: the buffer IS the embedding
+    assert rel_l2(pr.pixart_forward(sd, cfg, x, t, y, mask, sr.QSpec(quant=False), pe), g["fp"]) < 1e-5
+    spec = sr.QSpec(w_bits=8, fp_layers=pr.T2I_FP_LAYERS)
+    assert rel_l2(pr.pixart_forward(sd, cfg, x, t, y, mask, spec, pe), g["w8a8"]) < 1e-5
+    assert rel_l2(pr.pixart_forward(sd, cfg, x[:1], t[:1], y[:1], mask[:1], spec, pe), g["w8a8_b1"]) < 1e-5
+    qp = quant_params_of(g, "qp_naive")
+    wg = {n: (d.reshape(-1, 1), z.reshape(-1, 1)) for n, (d, z) in grids_of(qp, "weight_quantizer").items()}
+    spec_n = sr.QSpec(w_bits=8, fp_layers=pr.T2I_FP_LAYERS, act_mode="static", a_per_group=False,
+                      a_grid=grids_of(qp, "act_quantizer"), w_grid=wg)
+    assert rel_l2(pr.pixart_forward(sd, cfg, x, t, y, mask, spec_n, pe), g["naive"]) < 1e-5
+
+
+def test_tiny_pixart_w4a8_running_smooth_quant_statistic():
+    """BASELINE config 5 in miniature: 4-bit weights on the 4-bit grid, and the t2i scripts' arrangement of channel
+    balancing on the last block's mlp.fc2 only WITH its act-scale statistic still running at inference: the
+    statistic, s, W*s and the outputs move with every call (quant_txt2img.py:297-300, quant_layer.py:118-136)."""
+    from oracle import pixart_ref as pr
+    g = load_npz("tiny_pixart_w4a8.npz")
+    sd = state_dict_of(g)
+    cfg = dict(H=4, depth=2, patch=2, out_ch=8)
+    x, y, mask = g["x"], g["y"], g["mask"]
+    pe = load_npz("tiny_pixart_w8a8.npz")["pos_embed"]        # same geometry: hidden 64, 8 x 8 grid, base size 8
+    qp0 = quant_params_of(g, "qp_after_ptq")
+    wg = {n: (d.reshape(-1, 1), z.reshape(-1, 1)) for n, (d, z) in grids_of(qp0, "weight_quantizer").items()}
+    lname = "blocks.1.mlp.fc2"
+    spec = sr.QSpec(w_bits=4, fp_layers=pr.T2I_FP_LAYERS, w_grid=wg, alpha=0.3, timerange=[[0, 1000]],
+                    act_scale={lname: qp0[lname + ".act_quantizer"]["act_scale"].clone()}, running_stat=(lname,))
+    for j, tv in enumerate((820, 400, 90)):
+        out = pr.pixart_forward(sd, cfg, x, torch.tensor([tv, tv]), y, mask, spec, pe)
+        assert torch.allclose(spec.act_scale[lname], g["act_scale_after_call%d" % j], rtol=1e-5, atol=1e-7)
+        assert rel_l2(out, g["w4a8_call%d_t%d" % (j, tv)]) < 1e-5
+    spec.layer_w_bits = {"blocks.0.attn.qkv": 8, "blocks.1.mlp.fc1": 6}
+    out = pr.pixart_forward(sd, cfg, x, torch.tensor([820, 820]), y, mask, spec, pe)
+    assert rel_l2(out, g["w4a8_mp_call3_t820"]) < 1e-5
+
+
 def _import_dpm():
     """The solver is host logic of the product (pure torch, device-agnostic): load it by path so that this CPU
     test does not need the HIP library."""
@@ -205,3 +281,15 @@ def test_dpm_solver_schedule_and_trajectory_vs_reference():
                             model_kwargs=dict(data_info=None, mask=g["mask"][:1]))
     out = solver.sample(g["dpm_z"], steps=5, order=2, skip_type="time_uniform", method="multistep")
     assert rel_l2(out, g["dpm_final"]) < 1e-4
+    # the alpha entry point (quant_txt2img.py:133-138) on the alpha net, 4 steps
+    ga = load_npz("tiny_pixart_alpha.npz")
+    sda = state_dict_of(ga)
+    spec_a = sr.QSpec(w_bits=8, fp_layers=pr.T2I_FP_LAYERS)
+
+    def model_a(x, t, y, mask=None, **kw):                   # PixArt.forward_with_dpmsolver(x, timestep, y, mask)
+        m_ = mask if mask.shape[0] == y.shape[0] else mask.repeat(y.shape[0] // mask.shape[0], 1)
+        return pr.pixart_forward(sda, cfg, x, t, y, m_, spec_a, sda["pos_embed"]).chunk(2, dim=1)[0]
+    solver = dpm.DPMS_alpha(model_a, condition=ga["y"][:1], uncondition=ga["dpm_null_y"], cfg_scale=4.5,
+                            model_kwargs=dict(data_info=None, mask=ga["mask"][:1]))
+    out = solver.sample(ga["dpm_z"], steps=4, order=2, skip_type="time_uniform", method="multistep")
+    assert rel_l2(out, ga["dpm_final"]) < 1e-4
