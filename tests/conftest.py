@@ -35,3 +35,27 @@ def _no_grad():
     import torch
     with torch.no_grad():
         yield
+
+
+@pytest.fixture(scope="session")
+def parity():
+    """Recorder of ACHIEVED parity figures: tests put {name: {metric: value}}; written at session end to
+    gpurun_out/parity.json (copied into profiles/ by the author), so that every tolerance asserted in the GPU tests
+    can be read next to the value it bounds."""
+    import json
+    rec = {}
+    yield rec
+    if rec:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity.json")
+        old = {}
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    old = json.load(f)
+            except Exception:
+                old = {}
+        old.update(rec)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)

@@ -294,7 +294,8 @@ def _attn_ref(q, k, v, scale):
 
 
 @pytest.mark.parametrize("n_seq,L,H,D", [(2, 1024, 2, 72), (3, 100, 4, 16), (1, 256, 2, 64), (2, 65, 3, 32),
-                                         (5, 96, 8, 72), (300, 128, 16, 72)])   # last two: short fixed-length K/V -> register kernel
+                                         (5, 96, 8, 72), (300, 128, 16, 72),    # short fixed-length K/V -> register kernel
+                                         (2, 4096, 16, 72)])                    # PixArt-Sigma 1024^2: 4096 tokens, 16 heads of 72
 def test_attn_fwd_self(ops, dev, n_seq, L, H, D):
     Cc = H * D
     qkv = h16(n_seq * L, 3 * Cc, scale=1.0, seed=L + D).to(dev)
@@ -326,6 +327,35 @@ def test_attn_fwd_cross_varlen(ops, dev):
         s += Lb
     ref = torch.cat(outs).reshape(B * Nq, Cc)
     assert rel_l2(o.cpu().float(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("B,Nq,H,lens", [(2, 4096, 16, [300, 257]), (3, 777, 16, [129, 300, 17]), (1, 4096, 16, [300]),
+                                         (2, 100, 4, [300, 1])])
+def test_attn_cross_varlen_long_prompts(ops, dev, B, Nq, H, lens):
+    """PixArt-Sigma prompts: up to 300 T5 tokens (quant_txt2img.py:207-208) - more than the 128 keys the
+    register-resident kernel holds, so the general varlen kernel runs (bound = longest prompt, and unknown bound)."""
+    D = 72
+    Cc = H * D
+    q = h16(B * Nq, Cc, seed=Nq + 5).to(dev)
+    kv = h16(sum(lens), 2 * Cc, seed=7).to(dev)
+    offs = [0]
+    for L in lens:
+        offs.append(offs[-1] + L)
+    off = torch.tensor(offs, dtype=torch.int32, device=dev)
+    rows = torch.arange(0, Nq, max(1, Nq // 200))
+    qs = q.cpu().reshape(B, Nq, H, D)[:, rows]
+    outs = []
+    for b, Lb in enumerate(lens):
+        kb = kv[offs[b]:offs[b] + Lb, :Cc].cpu().reshape(1, Lb, H, D)
+        vb = kv[offs[b]:offs[b] + Lb, Cc:].cpu().reshape(1, Lb, H, D)
+        outs.append(_attn_ref(qs[b:b + 1], kb, vb, D ** -0.5))
+    ref = torch.cat(outs).reshape(B * len(rows), Cc)
+    for bound in (max(lens), 0):
+        o = torch.full_like(q, float("nan"))
+        ops.attn_fwd(q, kv, kv[:, Cc:], o, B, Nq, bound, H, D, Nq * Cc, Cc, 0, 2 * Cc, Nq * Cc, Cc, kv_off=off)
+        assert torch.isfinite(o).all()
+        got = o.cpu().float().reshape(B, Nq, Cc)[:, rows].reshape(B * len(rows), Cc)
+        assert rel_l2(got, ref) < 1e-3
 
 
 @pytest.mark.parametrize("B,Nq,H,lens", [(1, 16384, 16, [120]), (1, 1000, 16, [80]), (3, 203, 8, [17, 120, 1]),

@@ -1,0 +1,431 @@
+"""GPU parity of the plans and model families round 1 left untested, and the achieved-vs-asserted record.
+
+* static activation plans (w8a8_naive / *_ptqd: calibrated tensor-wise grids; the static per-token variant with
+  the zero-mask prompt path), PTQD with k != 0, the act-grid pass of the PTQ producer;
+* the PixArt-alpha net (BASELINE config 1) and PixArt-MS W4A8 with the running smooth-quant statistic (config 5);
+* full-size parity: one STDiT-XL/2 block at 16 x 1024 tokens (W8A8 and W4A8 timestep-aware) and one PixArt-XL/2 block at
+  4096 tokens / 300-token prompts / B = 2, each against the CPU oracle on identical weights;
+* every model-level comparison is made against the reference's fp32 output AND against the reference's own fp16-mode
+  output (what it computes on a GPU), and the achieved rel-L2 values go to gpurun_out/parity.json.
+
+Tolerances.  north_star: 1e-3 rel-L2.  Per LAYER that bound is asserted (test_model_gpu.py).  Above the layer level the
+reference itself, run the way its scripts run it (fp16 model and buffers), deviates from its fp32 result by
+1.0e-3 (block 0) ... 1.9e-3 (tiny model) ... 3.1e-3 (W4A8 tiny model): fp16 storage between layers flips
+quantization codes downstream.  The HIP path stores fp16 between kernels too, so the bound asserted here is
+"within 1.25 x the reference's own fp16-mode deviation from fp32" (and in absolute terms the figures recorded in
+profiles/r02_parity.json).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FP_LAYERS, grids_of, load_npz, quant_params_of, rel_l2, state_dict_of
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(input_size=(4, 8, 8), depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
+PIX_FP = ["x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder"]
+
+
+def _cfgs(w_bits, dynamic=True, per_group="token", smooth=None, mixed_precision=None, T=4, S=16, running_stat=False):
+    from viditq_amd.config import to_config
+    wq = dict(n_bits=w_bits, per_group="channel", channel_dim=0, scale_method="min_max", round_mode="nearest")
+    if mixed_precision:
+        wq["mixed_precision"] = mixed_precision
+    sq = dict(enable=False)
+    if smooth:
+        sq = dict(enable=True, channel_wise_scale_type="momentum_act_max", momentum=0.95, **smooth)
+    aq = dict(n_bits=8, per_group=per_group, scale_method="min_max", round_mode="nearest_ste", running_stat=running_stat,
+              dynamic=dynamic, sym=False, n_spatial_token=S, n_temporal_token=T, n_prompt=12, smooth_quant=sq)
+    return to_config(wq), to_config(aq)
+
+
+def _load_qp(qnn, qp):
+    from viditq_amd.qdiff.quantizer import BaseQuantizer
+    full = {mod.module_name: [qp.get(mod.module_name, {}), {}] for mod in qnn.model.modules()
+            if isinstance(mod, BaseQuantizer)}
+    qnn.set_quant_params_dict(full)
+    qnn.set_quant_init_done("weight")
+    qnn.set_quant_init_done("activation")
+    qnn.set_quant_state(True, True)
+
+
+def _stdit(gold, dev, wq, aq, cfg_split, fp=FP_LAYERS):
+    import viditq_amd  # noqa
+    from viditq_amd.qdiff.models import QuantModel
+    from viditq_amd.t2v import STDiT
+    m = STDiT(dtype=torch.float16, **TINY)
+    m.load_state_dict(state_dict_of(gold), strict=True)
+    qnn = QuantModel(m.half().to(dev).eval(), wq, aq)
+    qnn.set_module_name_for_quantizer(qnn.model)
+    qnn.fp_layer_list = list(fp)
+    qnn.cfg_split = cfg_split
+    return qnn
+
+
+def _rec(parity, name, got, ref32, ref16=None, **extra):
+    """achieved rel-L2 vs the reference's fp32 output, vs its fp16-mode output, and the reference's own fp16 deviation"""
+    ent = {"vs_ref_fp32": rel_l2(got, ref32)}
+    if ref16 is not None:
+        ent["vs_ref_fp16"] = rel_l2(got, ref16)
+        ent["ref_fp16_vs_ref_fp32"] = rel_l2(ref16, ref32)
+    ent.update(extra)
+    parity[name] = ent
+    return ent
+
+
+# ----------------------------------------------------------------------------- yardstick: the reference's fp16 mode
+def test_tiny_stdit_against_fp32_and_fp16_mode_goldens(dev, ops, parity):
+    """Every block output, the three forwards and the 3-step DDIM trajectory of the W8A8 tiny model; the W4A8
+    two-range / mixed-precision forwards and the 4-step MP trajectory: HIP path vs the reference in fp32 AND in its own
+    fp16 mode.  Asserted: not further from the fp32 result than 1.25 x the reference's fp16 mode is (+1e-4)."""
+    from test_model_gpu import _build
+    from viditq_amd.t2v import IDDPM
+    import viditq_amd.t2v.stdit as st
+    g, g16 = load_npz("tiny_stdit_w8a8.npz"), load_npz("tiny_stdit_fp16ref.npz")
+    qnn = _build(g, dev, 8)
+    x, y, mask, t = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev), g["t"].to(dev)
+    blocks = []
+    orig = st.STDiTBlock.forward_fused
+
+    def spy(self, x2, *a, **k):
+        r = orig(self, x2, *a, **k)
+        blocks.append(x2.clone())
+        return r
+    st.STDiTBlock.forward_fused = spy
+    try:
+        cond = qnn(x, t, y[:1], mask=mask).cpu()
+    finally:
+        st.STDiTBlock.forward_fused = orig
+    cases = [("w8a8_block%d" % i, b.cpu().float().reshape(1, 64, 64)) for i, b in enumerate(blocks)]
+    cases += [("w8a8_cond", cond), ("w8a8_uncond", qnn(x, t, y[1:], mask=mask).cpu()),
+              ("w8a8_joint", qnn(torch.cat([x, x]), torch.cat([t, t]), y, mask=mask).cpu())]
+    sch = IDDPM(num_sampling_steps=3, cfg_scale=4.0)
+    cases.append(("ddim_final", sch.ddim_sample_loop(qnn, g["ddim_z"].to(dev), dict(y=y, mask=mask)).cpu()))
+    for name, got in cases:
+        e = _rec(parity, "tiny_stdit/" + name, got, g[name], g16[name + "_ref_fp16"])
+        assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, (name, e)
+    # W4A8, two smooth-quant time-ranges, mixed precision
+    g = load_npz("tiny_stdit_w4a8.npz")
+    qnn = _build(g, dev, 4, smooth=dict(alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]]), mixed_precision=[4, 6, 8])
+    qnn.set_layer_smooth_quant(model=qnn, module_name_list=FP_LAYERS, smooth_quant=False, smooth_quant_running_stat=False)
+    x, y, mask = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev)
+    for tv in (721, 300):
+        got = qnn(x, torch.tensor([tv], device=dev), y[:1], mask=mask).cpu()
+        e = _rec(parity, "tiny_stdit/w4a8_cond_t%d" % tv, got, g["w4a8_cond_t%d" % tv], g16["w4a8_cond_t%d_ref_fp16" % tv])
+        assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
+    qnn.load_bitwidth_config(qnn, {"model.blocks.0.mlp.fc1": 8, "model.blocks.1.attn.q": 8}, "weight")
+    got = qnn(x, torch.tensor([721], device=dev), y[:1], mask=mask).cpu()
+    e = _rec(parity, "tiny_stdit/w4a8_mp_cond_t721", got, g["w4a8_mp_cond_t721"], g16["w4a8_mp_cond_t721_ref_fp16"])
+    assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
+    qnn.load_bitwidth_config(qnn, {"model.blocks.0.mlp.fc1": 4, "model.blocks.1.attn.q": 4}, "weight")
+    qnn.timestep_wise_mp = True
+    qnn.time_mp_config_weight = json.loads(g["mp_weight_cfg_json"])
+    qnn.time_mp_config_act = json.loads(g["mp_act_cfg_json"])
+    sch = IDDPM(num_sampling_steps=4, cfg_scale=4.0)
+    got = sch.ddim_sample_loop(qnn, g["mp_ddim_z"].to(dev), dict(y=g["mp_ddim_y"].half().to(dev), mask=mask)).cpu()
+    e = _rec(parity, "tiny_stdit/mp_ddim_final", got, g["mp_ddim_final"], g16["mp_ddim_final_ref_fp16"])
+    # a trajectory's deviation is dominated by WHICH codes flip, not how many: 2 x the reference's own figure
+    assert e["vs_ref_fp32"] < 2.0 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
+
+
+# ----------------------------------------------------------------------------- static activation plans (A3)
+@pytest.mark.parametrize("tag,per_group", [("tw", False), ("tk", "token")])
+def test_static_activation_plans_match_reference(dev, ops, parity, tag, per_group):
+    """w8a8_naive / *_ptqd (``per_group: False, dynamic: False``, cfg_split False): the calibrated grids of the
+    reference, loaded through the ckpt.pth schema, must be the grids the HIP path quantizes on - on the fused route
+    (tensor-wise) and, for static per-token grids, on the layer-by-layer route with the zero-mask prompt path
+    (stdit.py:272-301) and the [B, n_prompt, C] kv view (stdit_quant_layer.py:272-278)."""
+    g = load_npz("tiny_stdit_static.npz")
+    wq, aq = _cfgs(8, dynamic=False, per_group=per_group, mixed_precision=[4, 6, 8])
+    qnn = _stdit(g, dev, wq, aq, cfg_split=False)
+    _load_qp(qnn, quant_params_of(g, "qp_" + tag))
+    fused = all(b.fused_ok() for b in qnn.model.blocks)
+    assert fused == (tag == "tw")
+    assert qnn.model._mask_select() == (tag == "tw")
+    x, y, mask = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev)
+    t = torch.tensor([721, 721], device=dev)
+    joint = qnn(torch.cat([x, x]), t, y, mask=mask).cpu()
+    e = _rec(parity, "tiny_stdit_static/%s_joint_t721" % tag, joint, g[tag + "_joint_t721"], g[tag + "_joint_t721_ref_fp16"])
+    assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
+    cond = qnn(x, torch.tensor([300], device=dev), y[:1], mask=mask).cpu()
+    e = _rec(parity, "tiny_stdit_static/%s_cond_t300" % tag, cond, g[tag + "_cond_t300"])
+    assert e["vs_ref_fp32"] < 3e-3, e
+    if tag == "tw":
+        # a dynamic grid silently substituted for the calibrated one would land ~1e-2 away
+        wq_d, aq_d = _cfgs(8, mixed_precision=[4, 6, 8])
+        qd = _stdit(g, dev, wq_d, aq_d, cfg_split=False)
+        _load_qp(qd, {k: v for k, v in quant_params_of(g, "qp_tw").items() if k.endswith("weight_quantizer")})
+        dyn = qd(torch.cat([x, x]), t, y, mask=mask).cpu()
+        assert rel_l2(dyn, g["tw_joint_t721"]) > 2 * e["vs_ref_fp32"]
+
+
+def test_ptqd_ddim_with_nonzero_k_matches_reference(dev, ops, parity):
+    """PTQD correlated-noise correction (iddpm/__init__.py:168-172): every model output divided by
+    1 + ks[(999 - t) // 50] with a NON-zero table, 3 guided DDIM steps of the static tensor-wise plan."""
+    from viditq_amd.t2v import IDDPM
+    g = load_npz("tiny_stdit_static.npz")
+    wq, aq = _cfgs(8, dynamic=False, per_group=False, mixed_precision=[4, 6, 8])
+    qnn = _stdit(g, dev, wq, aq, cfg_split=False)
+    _load_qp(qnn, quant_params_of(g, "qp_tw"))
+    sch = IDDPM(num_sampling_steps=3, cfg_scale=4.0)
+    assert sch.timestep_map == [int(v) for v in g["tw_ptqd_timestep_map"]]
+    y, mask = g["y"].half().to(dev), g["mask"].to(dev)
+    out = sch.ddim_sample_loop(qnn, g["ddim_z"].to(dev), dict(y=y, mask=mask), ks=g["ks"]).cpu()
+    e = _rec(parity, "tiny_stdit_static/tw_ptqd_ddim_final", out, g["tw_ptqd_ddim_final"], g["tw_ptqd_ddim_final_ref_fp16"])
+    assert e["vs_ref_fp32"] < 2.0 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
+    out0 = sch.ddim_sample_loop(qnn, g["ddim_z"].to(dev), dict(y=y, mask=mask)).cpu()      # k = 0 is a different result
+    assert rel_l2(out0, g["tw_ptqd_ddim_final"]) > 10 * e["vs_ref_fp32"]
+
+
+@pytest.mark.parametrize("tag,per_group", [("tw", False), ("tk", "token")])
+def test_ptq_calibrate_static_activation_grids(dev, ops, tag, per_group):
+    """Pass 3 of ptq.calibrate (t2v/scripts/ptq.py:296-318): static activation grids re-initialised by every
+    calibration batch, the last one stays - against the grids the reference classes produced on the same batches."""
+    from viditq_amd import ptq
+    from viditq_amd.config import to_config
+    g = load_npz("tiny_stdit_static.npz")
+    wq, aq = _cfgs(8, dynamic=False, per_group=per_group, mixed_precision=[4, 6, 8])
+    qnn = _stdit(g, dev, wq, aq, cfg_split=False)
+    del qnn.fp_layer_list
+    cfg = to_config({"calib_data": {"n_samples": 1, "batch_size": 1, "n_steps": 3},
+                     "quant": {"weight": {"quantizer": wq}, "activation": {"quantizer": aq}}})
+    data = (g["calib_xs"], g["calib_ts"], g["calib_cs"].half(), g["calib_masks"])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # the static per-token kv grid hits the reference's eps fill (expected)
+        qd = ptq.calibrate(qnn, cfg, data, fp_layer_list=FP_LAYERS)
+    ref = quant_params_of(g, "qp_" + tag)
+    n = 0
+    for name, (bufs, _) in qd.items():
+        if not name.startswith("blocks") or not name.endswith("act_quantizer"):
+            continue
+        a, b = bufs["delta"].float().cpu(), ref[name]["delta"].float()
+        # fp16 activations vs the reference's fp32: min / max of an activation tensor agree to fp16 rounding of the
+        # extreme element plus upstream code flips
+        assert torch.allclose(a.reshape(b.shape), b, rtol=2e-2, atol=1e-7), (name, float((a.reshape(b.shape) - b).abs().max()))
+        za, zb = bufs["zero_point"].float().cpu(), ref[name]["zero_point"].float()
+        assert (za.reshape(zb.shape) - zb).abs().max() <= 3, name
+        n += 1
+    assert n == 2 * 13
+    if per_group == "token":
+        assert torch.all(qd["blocks.0.cross_attn.kv_linear.act_quantizer"][0]["delta"] == 1e-6)   # global eps fill
+    x, y, mask = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev)
+    out = qnn(torch.cat([x, x]), torch.tensor([721, 721], device=dev), y, mask=mask).cpu()
+    assert rel_l2(out, g[tag + "_joint_t721"]) < 2e-2      # own calibration: grids differ in the last bits -> other codes
+
+
+# ----------------------------------------------------------------------------- PixArt-alpha (config 1)
+def _pixart(cls_name, gold, dev, wq, aq):
+    import viditq_amd  # noqa
+    from viditq_amd import t2i
+    from viditq_amd.qdiff.models import QuantModel
+    m = getattr(t2i, cls_name)(input_size=16, depth=2, hidden_size=64, num_heads=4, model_max_length=12,
+                               caption_channels=32, dtype=torch.float16)
+    m.load_state_dict(state_dict_of(gold), strict=True)
+    qnn = QuantModel(m.half().to(dev).eval(), wq, aq, model_type="pixart")
+    qnn.set_module_name_for_quantizer(qnn.model)
+    qnn.fp_layer_list = list(PIX_FP)
+    return qnn
+
+
+def test_pixart_alpha_net_matches_reference(dev, ops, parity):
+    """BASELINE config 1 (PixArt-alpha 256^2 W8A8): ``PixArt`` is the alpha class of PixArt.py:63-256 - fixed
+    pos_embed buffer, PixArtBlock - not an alias of the multi-scale net.  FP, W8A8 dynamic (B = 2 shared scales and
+    the single-prompt B = 1 case on the fused route), the static 'naive' plan, and a DPM-Solver++ trajectory through
+    the alpha entry point."""
+    from viditq_amd import t2i
+    from viditq_amd.t2i.dpm_solver import DPMS_alpha
+    assert t2i.PixArt is not t2i.PixArtMS and not issubclass(t2i.PixArt, t2i.PixArtMS)
+    g = load_npz("tiny_pixart_alpha.npz")
+    wq, aq = _cfgs(8, T=1, S=64)
+    qnn = _pixart("PixArt", g, dev, wq, aq)
+    assert type(qnn.model.blocks[0]).__name__ == "PixArtBlock"
+    assert torch.equal(qnn.model.pos_embed.cpu().float(), state_dict_of(g)["pos_embed"])
+    x, y, mask, t = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev), g["t"].to(dev)
+    assert rel_l2(qnn(x, t, y, mask=mask).cpu().float(), g["fp"]) < 3e-3          # FP model, fp16 storage
+    _load_qp(qnn, quant_params_of(g, "qp"))
+    assert all(b.fused_ok() for b in qnn.model.blocks)
+    e = _rec(parity, "tiny_pixart_alpha/w8a8", qnn(x, t, y, mask=mask).cpu().float(), g["w8a8"])
+    assert e["vs_ref_fp32"] < 5e-3, e
+    out1 = qnn(x[:1], t[:1], y[:1], mask=mask[:1]).cpu().float()
+    e = _rec(parity, "tiny_pixart_alpha/w8a8_b1", out1, g["w8a8_b1"], g["w8a8_b1_ref_fp16"])
+    assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
+    solver = DPMS_alpha(qnn.forward_with_dpmsolver, condition=g["y"][:1].half().to(dev),
+                        uncondition=g["dpm_null_y"].half().to(dev), cfg_scale=4.5,
+                        model_kwargs=dict(data_info=None, mask=g["mask"][:1].to(dev)))
+    out = solver.sample(g["dpm_z"].to(dev), steps=4, order=2, skip_type="time_uniform", method="multistep")
+    e = _rec(parity, "tiny_pixart_alpha/dpm_final", out.cpu().float(), g["dpm_final"])
+    assert e["vs_ref_fp32"] < 2e-2, e
+    # static tensor-wise plan (alpha/w8a8_naive.yaml) on the fused route
+    wq, aq = _cfgs(8, dynamic=False, per_group=False, T=1, S=64)
+    qn = _pixart("PixArt", g, dev, wq, aq)
+    _load_qp(qn, quant_params_of(g, "qp_naive"))
+    assert all(b.fused_ok() for b in qn.model.blocks)
+    e = _rec(parity, "tiny_pixart_alpha/naive", qn(x, t, y, mask=mask).cpu().float(), g["naive"])
+    assert e["vs_ref_fp32"] < 5e-3, e
+
+
+def test_pixart_w4a8_running_smooth_quant_statistic(dev, ops, parity):
+    """BASELINE config 5 in miniature (PixArt-MS, 4-bit weights with grids for [4,6,8], dynamic 8-bit activations) with
+    the t2i scripts' smooth-quant arrangement: channel balancing on the last block's mlp.fc2 only, its act-scale
+    statistic still RUNNING at inference (quant_txt2img.py:297-300).  Every call moves the statistic, hence s and
+    W*s: the layer must re-derive and re-pack (stale cache), the other block stays on the fused route."""
+    g = load_npz("tiny_pixart_w4a8.npz")
+    wq, aq = _cfgs(4, T=1, S=64, smooth=dict(alpha=0.3), mixed_precision=[4, 6, 8])
+    qnn = _pixart("PixArtMS", g, dev, wq, aq)
+    qnn.set_smooth_quant(smooth_quant=False, smooth_quant_running_stat=False)
+    qnn.set_layer_smooth_quant(model=qnn, module_name_list=["blocks.1.mlp.fc2"], smooth_quant=True,
+                               smooth_quant_running_stat=True)
+    _load_qp(qnn, quant_params_of(g, "qp_after_ptq"))
+    assert qnn.model.blocks[0].fused_ok() and not qnn.model.blocks[1].fused_ok()
+    fc2 = qnn.model.blocks[1].mlp.fc2
+    x, y, mask = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev)
+    for j, tv in enumerate((820, 400, 90)):
+        out = qnn(x, torch.tensor([tv, tv], device=dev), y, mask=mask).cpu().float()
+        a, b = fc2.act_quantizer.act_scale.cpu().float(), g["act_scale_after_call%d" % j]
+        assert torch.allclose(a.reshape(b.shape), b, rtol=2e-2, atol=1e-4)             # max|x| of fp16 activations
+        e = _rec(parity, "tiny_pixart_w4a8/call%d_t%d" % (j, tv), out, g["w4a8_call%d_t%d" % (j, tv)])
+        assert e["vs_ref_fp32"] < 1e-2, e                                             # 4-bit weights (cf. W4A8 STDiT)
+    qnn.load_bitwidth_config(qnn, {"model.blocks.0.attn.qkv": 8, "model.blocks.1.mlp.fc1": 6}, "weight")
+    out = qnn(x, torch.tensor([820, 820], device=dev), y, mask=mask).cpu().float()
+    e = _rec(parity, "tiny_pixart_w4a8/mp_call3_t820", out, g["w4a8_mp_call3_t820"])
+    assert e["vs_ref_fp32"] < 1e-2, e
+    assert qnn.model.blocks[0].attn.qkv.packed_weight(0).n_bits == 8
+
+
+# ----------------------------------------------------------------------------- full-size blocks vs the oracle
+def _sd_of(m):
+    return {k: v.detach().cpu().float() for k, v in m.state_dict().items()
+            if "weight_quantizer" not in k and "act_quantizer" not in k}
+
+
+@pytest.mark.parametrize("plan", ["w8a8", "w4a8"])
+def test_full_size_stdit_block_matches_oracle(dev, ops, parity, plan):
+    """ONE STDiT-XL/2 block at the benchmark's size - 16 frames x 1024 tokens, C = 1152, 16 heads of 72, mlp 4608, 97
+    prompt tokens - through the fused HIP route vs the CPU oracle on identical weights (BASELINE configs 2 and 3).
+    W4A8 = the timestep-aware plan: 4-bit weights, two smooth-quant time-ranges, grids of range 0."""
+    import viditq_amd  # noqa
+    from viditq_amd import synth
+    from viditq_amd.config import loads_yaml
+    from oracle import stdit_ref as sr
+    m = synth.build_stdit(dev, depth=1, caption_channels=64, seed=11)
+    cfg = loads_yaml(synth.W8A8_DYNAMIC if plan == "w8a8" else synth.W4A8_TIMESTEP_AWARE)
+    qnn = synth.quantize_model(m, cfg)
+    assert all(b.fused_ok() for b in qnn.model.blocks)
+    gx = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 4, 16, 64, 64, generator=gx).to(dev)
+    y = (torch.randn(1, 1, 120, 64, generator=gx) * 0.3).half().to(dev)
+    mask = torch.zeros(1, 120, dtype=torch.int64)
+    mask[0, :97] = 1
+    import viditq_amd.t2v.stdit as st
+    blocks = []
+    orig = st.STDiTBlock.forward_fused
+
+    def spy(self, x2, *a, **k):
+        r = orig(self, x2, *a, **k)
+        blocks.append(x2.clone())
+        return r
+    sd = _sd_of(m)
+    cfgd = dict(T=16, S=1024, H=16, depth=1, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(16, 64, 64))
+    spec = sr.QSpec(w_bits=8)
+    if plan == "w4a8":
+        act_scale = {n: l.act_quantizer.act_scale.detach().cpu().float() for n, l in qnn.quant_layers()
+                     if n.startswith("blocks") and getattr(l.act_quantizer, "act_scale", None) is not None}
+        assert len(act_scale) == 13
+        spec = sr.QSpec(w_bits=4, act_scale=act_scale, alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]])
+    for tv in ((721,) if plan == "w8a8" else (721, 300)):
+        t = torch.tensor([tv], device=dev)
+        blocks.clear()
+        st.STDiTBlock.forward_fused = spy
+        try:
+            out = qnn(x, t, y, mask=mask.to(dev)).cpu()
+        finally:
+            st.STDiTBlock.forward_fused = orig
+        ref, rblocks = sr.stdit_forward(sd, cfgd, x.cpu().half().float(), t.cpu(), y.cpu().float(), mask, spec,
+                                        return_blocks=True)
+        eb = _rec(parity, "full_size/stdit_block_%s_t%d" % (plan, tv), blocks[0].cpu().float().reshape(1, 16384, 1152),
+                  rblocks[0], tokens=16384, C=1152)
+        eo = _rec(parity, "full_size/stdit_depth1_model_%s_t%d" % (plan, tv), out, ref)
+        # ~20 kernels with fp16 storage between them; the reference's own fp16 mode is 1.0e-3 from fp32 on a block
+        assert eb["vs_ref_fp32"] < (2e-3 if plan == "w8a8" else 4e-3), eb
+        assert eo["vs_ref_fp32"] < (3e-3 if plan == "w8a8" else 6e-3), eo
+    assert qnn.check_status() == 0
+
+
+def test_full_size_pixart_block_n4096_lp300_matches_oracle(dev, ops, parity):
+    """ONE PixArt-XL/2 block at PixArt-Sigma 1024^2 size (BASELINE config 5): 4096 image tokens, prompts of up to 300
+    tokens, B = 2 (uncond | cond batched as the t2i loop does: per-token scales shared over the batch), 4-bit weights,
+    dynamic 8-bit activations - fused HIP route vs the CPU oracle.  Exercises the 4096-token flash attention and the
+    varlen cross attention beyond the 128-key register kernel at model level."""
+    import viditq_amd  # noqa
+    from viditq_amd import synth, t2i
+    from viditq_amd.qdiff.models import QuantModel
+    from oracle import pixart_ref as pr
+    from oracle import stdit_ref as sr
+    torch.manual_seed(21)
+    m = t2i.PixArtMS(input_size=128, depth=1, hidden_size=1152, num_heads=16, model_max_length=300, caption_channels=64,
+                     pe_interpolation=2.0, dtype=torch.float16)
+    synth.redraw_zero_init(m, 22)
+    m = m.half().to(dev).eval()
+    wq, aq = _cfgs(4, T=1, S=4096, mixed_precision=[4, 6, 8])
+    qnn = QuantModel(m, wq, aq, model_type="pixart")
+    qnn.set_module_name_for_quantizer(qnn.model)
+    qnn.fp_layer_list = list(PIX_FP)
+    for _, layer in qnn.quant_layers():
+        layer.weight_quantizer(layer.weight.detach())
+    qnn.set_quant_init_done("weight")
+    qnn.set_quant_init_done("activation")
+    qnn.set_quant_state(True, True)
+    assert all(b.fused_ok() for b in qnn.model.blocks)
+    gx = torch.Generator().manual_seed(23)
+    x = torch.randn(2, 4, 128, 128, generator=gx).to(dev)
+    y = (torch.randn(2, 1, 300, 64, generator=gx) * 0.3).half().to(dev)
+    mask = torch.zeros(2, 300, dtype=torch.int64)
+    mask[0, :300] = 1
+    mask[1, :143] = 1
+    t = torch.tensor([500, 500], device=dev)
+    out = qnn(x, t, y, mask=mask.to(dev)).cpu().float()
+    sd = _sd_of(m)
+    pe = qnn.model._pos_embed(dev, torch.float16).cpu().float()
+    spec = sr.QSpec(w_bits=4, fp_layers=pr.T2I_FP_LAYERS)
+    ref = pr.pixart_forward(sd, dict(H=16, depth=1, patch=2, out_ch=8), x.cpu().half().float(), t.cpu(), y.cpu().float(),
+                            mask, spec, pe)
+    e = _rec(parity, "full_size/pixart_depth1_model_w4a8_n4096_lp300_b2", out, ref, tokens=4096, prompt_tokens=[300, 143])
+    assert e["vs_ref_fp32"] < 8e-3, e            # 4-bit weights + quantized final layer (cf. tiny W4A8: 3e-3 in fp16 mode)
+    assert qnn.check_status() == 0
+
+
+# ----------------------------------------------------------------------------- eps-fill probe at model level
+def test_kv_linear_eps_fill_is_flagged_at_model_level(dev, ops):
+    """Prompt embeddings are NOT normalised: a prompt token whose embedded row is (near-)constant makes the
+    reference set EVERY token's step of cross_attn.kv_linear to 1e-6 (base_quantizer.py:220-222) - zero points of
+    ~1e6 and saturated codes, which int32 row terms cannot even represent.  The integer route keeps per-token grids
+    instead (the one deliberate deviation) and MUST say so: status bit + warning, or an exception on request."""
+    import warnings
+    import viditq_amd  # noqa
+    from viditq_amd import synth
+    from viditq_amd.config import loads_yaml
+    m = synth.build_stdit(dev, depth=1, hidden_size=64, num_heads=4, input_size=(4, 8, 8), model_max_length=12,
+                          caption_channels=32, seed=5)
+    with torch.no_grad():
+        m.y_embedder.y_proj.fc1.bias.zero_()
+        m.y_embedder.y_proj.fc2.bias.zero_()
+    qnn = synth.quantize_model(m, loads_yaml(synth.W8A8_DYNAMIC))
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 4, 4, 8, 8, generator=g).to(dev)
+    y = (torch.randn(1, 1, 12, 32, generator=g) * 0.3).half().to(dev)
+    mask = torch.ones(1, 12, dtype=torch.int64, device=dev)
+    qnn(x, torch.tensor([500], device=dev), y, mask=mask)
+    assert qnn.check_status() == 0
+    y[0, 0, 3] = 0                                  # an all-zero prompt token -> embedded row 0 -> step 0 < 1e-6
+    out = qnn(x, torch.tensor([500], device=dev), y, mask=mask)
+    assert torch.isfinite(out).all()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert qnn.check_status() & 1
+    assert any("1e-6" in str(i.message) for i in w)
+    with pytest.raises(RuntimeError):
+        qnn.check_status(raise_on_eps=True)

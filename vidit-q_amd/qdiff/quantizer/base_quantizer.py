@@ -89,6 +89,10 @@ class BaseQuantizer(nn.Module):
     def _params_2d(self, x2d: torch.Tensor, n_bits: int, smooth=None):
         """min-max (delta, zp) per row of an fp16 [G, E] matrix (times ``smooth`` [E] in fp32) incl. the
         global eps fill."""
+        if self.momentum:
+            if smooth is not None:
+                raise NotImplementedError("running_stat on a smoothed weight")
+            return self._params_momentum(x2d, n_bits)
         x2d = x2d.contiguous()
         if x2d.dtype != torch.float16:
             x2d = x2d.half()
@@ -99,11 +103,30 @@ class BaseQuantizer(nn.Module):
             delta, zp = ops.weight_minmax(x2d, n_bits, s=smooth, force_eps=True)
         return delta, zp
 
+    def _params_momentum(self, x2d: torch.Tensor, n_bits: int):
+        """``running_stat: True`` (t2i sigma/*_naive.yaml): momentum average of the group min / max over the
+        calibration calls, then the same min-max formulas (base_quantizer.py:191-228).  The average is updated once
+        per CALL of init_quant_params - with a ``mixed_precision`` list that is once per listed bit-width and
+        forward, as released.  Calibration-time only: plain fp32 torch arithmetic (the reference's own ops)."""
+        x2d = x2d.float()
+        x_min = x2d.amin(dim=-1).clamp(max=0.0)
+        x_max = x2d.amax(dim=-1).clamp(min=0.0)
+        if not hasattr(self, "x_min"):
+            self.x_min, self.x_max = x_min, x_max
+        else:
+            self.x_min = self.x_min * self.momentum + x_min * (1 - self.momentum)
+            self.x_max = self.x_max * self.momentum + x_max * (1 - self.momentum)
+            x_min, x_max = self.x_min, self.x_max
+        delta = (x_max - x_min) / (2 ** n_bits - 1)
+        if delta.min() < 1.0e-6:
+            delta = torch.full_like(delta, 1.0e-6)
+            self._warn_eps()
+        return delta, torch.round(-x_min / delta)
+
     def init_quant_params(self, x: torch.Tensor, per_group=False, momentum=False, n_bits=None, smooth=None):
         """Min-max init for one bit-width; mirrors base_quantizer.py:146-290.  ``smooth`` [K] fp32
-        multiplies a 2-D weight in fp32 inside the kernel (W * channel_wise_scale, quant_layer.py:183)."""
-        if momentum:
-            raise NotImplementedError("running_stat momentum is False in every shipped config")
+        multiplies a 2-D weight in fp32 inside the kernel (W * channel_wise_scale, quant_layer.py:183).
+        ``momentum`` is accepted and, as in the reference (:196), ignored in favour of ``self.momentum``."""
         i_bitwidth = list(self.mixed_precision).index(n_bits) if (self.mixed_precision is not None and n_bits) else 0
         if n_bits is None:
             n_bits = self.n_bits
