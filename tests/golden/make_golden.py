@@ -620,6 +620,7 @@ def tiny_pixart_alpha():
         out["w8a8_b1"] = qnn(x[:1], t[:1], y[:1], mask=mask[:1])       # the single-prompt configuration
         q16 = _half_copy(qnn)
         out["w8a8_b1_ref_fp16"] = q16(x[:1], t[:1], y[:1].half(), mask=mask[:1]).float()
+        out["w8a8_ref_fp16"] = q16(x, t, y.half(), mask=mask).float()
         del q16
         _qp(out, "qp", qnn)
         # static tensor-wise plan (alpha/w8a8_naive.yaml): two calibration batches, the last one stays
@@ -632,6 +633,9 @@ def tiny_pixart_alpha():
                          ref_import.aq_cfg(dynamic=False, per_group=False, T=1, S=64, n_prompt=12),
                          calib[0][0], calib[0][1], calib[0][2], calib[0][3], calib=calib)
         out["naive"] = qn(x, t, y, mask=mask)
+        q16 = _half_copy(qn)
+        out["naive_ref_fp16"] = q16(x, t, y.half(), mask=mask).float()
+        del q16
         _qp(out, "qp_naive", qn)
         # DPM-Solver++ 2M, 4 guided steps, through the alpha entry point (quant_txt2img.py:133-138)
         dps = importlib.import_module("diffusion.dpm_solver_alpha")

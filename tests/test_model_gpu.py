@@ -121,7 +121,7 @@ def test_smooth_quant_two_ranges_w4_matches_reference(dev, ops):
 
 
 # ----------------------------------------------------------------------------- tiny STDiT vs reference goldens
-def test_tiny_stdit_w8a8_fused_path(dev, ops):
+def test_tiny_stdit_w8a8_fused_path(dev, ops, parity):
     g = load_npz("tiny_stdit_w8a8.npz")
     qnn = _build(g, dev, 8)
     assert all(b.fused_ok() for b in qnn.model.blocks)
@@ -140,14 +140,15 @@ def test_tiny_stdit_w8a8_fused_path(dev, ops):
         cond = qnn(x, t, y[:1], mask=mask)
     finally:
         st.STDiTBlock.forward_fused = orig
-    # block outputs: fp16 storage between ~20 kernels, code flips downstream -> 3e-3
+    # block outputs: fp16 storage between ~20 kernels flips codes downstream.  Recorded (profiles/r02_parity.json):
+    # 8.1e-4 / 1.17e-3 vs the reference's own fp16 mode at 1.0e-3 / 1.4e-3; asserted at 1.25 x the recorded values
     for i, bk in enumerate(blocks):
-        assert rel_l2(bk.cpu().float().reshape(1, 64, 64), g["w8a8_block%d" % i]) < 3e-3
+        assert rel_l2(bk.cpu().float().reshape(1, 64, 64), g["w8a8_block%d" % i]) < (1.0e-3, 1.5e-3)[i]
     assert cond.dtype == torch.float32 and cond.shape == g["w8a8_cond"].shape
-    assert rel_l2(cond.cpu(), g["w8a8_cond"]) < 5e-3
-    assert rel_l2(qnn(x, t, y[1:], mask=mask).cpu(), g["w8a8_uncond"]) < 5e-3
+    assert rel_l2(cond.cpu(), g["w8a8_cond"]) < 1.95e-3             # recorded 1.53e-3 (reference fp16 mode: 1.94e-3)
+    assert rel_l2(qnn(x, t, y[1:], mask=mask).cpu(), g["w8a8_uncond"]) < 1.95e-3
     joint = qnn(torch.cat([x, x]), torch.cat([t, t]), y, mask=mask)   # cfg_split False: scales shared over B=2
-    assert rel_l2(joint.cpu(), g["w8a8_joint"]) < 5e-3
+    assert rel_l2(joint.cpu(), g["w8a8_joint"]) < 1.95e-3
     assert qnn.check_status() == 0
     # yardstick: the reference's OWN fp16 mode (model.half(), as it runs on a GPU) deviates from its
     # fp32 result by fp16-storage rounding + downstream code flips; the HIP path must not be worse
@@ -167,8 +168,8 @@ def test_tiny_stdit_layerwise_equals_fused(dev, ops):
         layerwise = qnn(x, t, y[:1], mask=mask)
     finally:
         st.STDiTBlock.fused_ok = orig
-    assert rel_l2(layerwise.cpu(), fused.cpu()) < 5e-3
-    assert rel_l2(layerwise.cpu(), g["w8a8_cond"]) < 5e-3
+    assert rel_l2(layerwise.cpu(), fused.cpu()) < 2.5e-3
+    assert rel_l2(layerwise.cpu(), g["w8a8_cond"]) < 2.5e-3
     qnn.set_quant_state(False, False)                           # FP model through the layerwise route
     assert rel_l2(qnn(x, t, y[:1], mask=mask).cpu(), g["fp_cond"]) < 3e-3
 
@@ -183,10 +184,10 @@ def test_tiny_stdit_w4a8_timerange_and_mixed_precision(dev, ops):
     x, y, mask = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev)
     for tv in (721, 300):
         out = qnn(x, torch.tensor([tv], device=dev), y[:1], mask=mask)
-        assert rel_l2(out.cpu(), g["w4a8_cond_t%d" % tv]) < 1e-2   # 4-bit weights: larger steps, same flips
+        assert rel_l2(out.cpu(), g["w4a8_cond_t%d" % tv]) < 1.55e-3   # recorded 1.2e-3 (reference fp16 mode: 2.7 - 3.1e-3)
     qnn.load_bitwidth_config(qnn, {"model.blocks.0.mlp.fc1": 8, "model.blocks.1.attn.q": 8}, "weight")
     out = qnn(x, torch.tensor([721], device=dev), y[:1], mask=mask)
-    assert rel_l2(out.cpu(), g["w4a8_mp_cond_t721"]) < 1e-2
+    assert rel_l2(out.cpu(), g["w4a8_mp_cond_t721"]) < 1.55e-3
     assert qnn.model.blocks[0].mlp.fc1.packed_weight(1).n_bits == 8
 
 
@@ -214,7 +215,7 @@ def test_timestep_wise_mixed_precision_ddim(dev, ops, graphed):
                                     qnn.model.blocks[1].attn.q.weight_quantizer.n_bits,
                                     qnn.model.blocks[0].attn_temp.q.get_quant_state())))
     assert seen == [(8, 4, (False, False))] * 2 + [(4, 6, (True, True))] * 2
-    assert rel_l2(out.cpu(), g["mp_ddim_final"]) < 2e-2       # 4 steps x 4-bit weights: rounding flips compound
+    assert rel_l2(out.cpu(), g["mp_ddim_final"]) < 8.0e-4     # recorded 6.4e-4 (reference fp16 mode: 7.8e-4)
 
 
 def test_ptq_calibrate_reproduces_reference_quant_params(dev, ops, tmp_path):
@@ -295,10 +296,10 @@ def test_ddim_loop_matches_reference_trajectory(dev, ops):
     assert s100.timestep_map == [int(v) for v in g["tmap100"]] and np.allclose(s100.alphas_cumprod, g["acp100"], rtol=1e-14)
     z = g["ddim_z"].to(dev)
     out = sch.ddim_sample_loop(qnn, z, dict(y=g["y"].half().to(dev), mask=g["mask"].to(dev)))
-    assert rel_l2(out.cpu(), g["ddim_final"]) < 1e-2            # 6 quantized forwards chained
+    assert rel_l2(out.cpu(), g["ddim_final"]) < 9.5e-4          # recorded 7.6e-4 (reference fp16 mode: 8.4e-4)
 
 
-def test_block_matches_oracle_at_xl_width(dev, ops):
+def test_block_matches_oracle_at_xl_width(dev, ops, parity):
     """One STDiT-XL/2-width block (C=1152, 16 heads of 72, mlp 4608) at reduced token count
     (T=4, S=64) through the fused path vs the oracle on identical weights."""
     import viditq_amd  # noqa
@@ -319,7 +320,8 @@ def test_block_matches_oracle_at_xl_width(dev, ops):
           and "act_quantizer" not in k}
     cfgd = dict(T=4, S=64, H=16, depth=1, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(4, 16, 16))
     ref = sr.stdit_forward(sd, cfgd, x.cpu().half().float(), t.cpu(), y.cpu().float(), mask, sr.QSpec(w_bits=8))
-    assert rel_l2(out.cpu(), ref) < 5e-3
+    parity["xl_width/stdit_depth1_model_w8a8_256tok"] = {"vs_ref_fp32": rel_l2(out.cpu(), ref)}
+    assert rel_l2(out.cpu(), ref) < 1.25e-3                     # recorded 9.9e-4
 
 
 def test_hip_graph_two_stream_step_equals_eager(dev, ops):
@@ -341,7 +343,7 @@ def test_hip_graph_two_stream_step_equals_eager(dev, ops):
     assert len(gs.graphs) == 1
 
 
-def test_tiny_pixart_w8a8_fused_path(dev, ops):
+def test_tiny_pixart_w8a8_fused_path(dev, ops, parity):
     """PixArt-MS through QuantModel(model_type='pixart') vs the reference golden: fused-qkv
     QuantAttnLinearImg, varlen cross attention, quantized final_layer (t2i FP list), B = 2 shared scales."""
     import viditq_amd  # noqa
@@ -371,9 +373,11 @@ def test_tiny_pixart_w8a8_fused_path(dev, ops):
     assert qnn.model.final_layer.linear.get_quant_state() == (True, True)
     x, y, mask, t = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev), g["t"].to(dev)
     out = qnn(x, t, y, mask=mask)
-    assert rel_l2(out.cpu().float(), g["w8a8"]) < 5e-3
     out1 = qnn(x[:1], t[:1], y[:1], mask=mask[:1])
-    assert rel_l2(out1.cpu().float(), g["w8a8_b1"]) < 5e-3
+    parity["tiny_pixart_ms/w8a8"] = {"vs_ref_fp32": rel_l2(out.cpu().float(), g["w8a8"])}
+    parity["tiny_pixart_ms/w8a8_b1"] = {"vs_ref_fp32": rel_l2(out1.cpu().float(), g["w8a8_b1"])}
+    assert rel_l2(out.cpu().float(), g["w8a8"]) < 4.5e-3         # recorded 3.6e-3 (this tiny net is the sensitive one:
+    assert rel_l2(out1.cpu().float(), g["w8a8_b1"]) < 4.1e-3     # recorded 3.3e-3; the reference's fp16 mode sits at 4.9e-3)
     qnn.set_quant_state(False, False)
     assert rel_l2(qnn(x, t, y, mask=mask).cpu().float(), g["fp"]) < 3e-3
 
@@ -431,7 +435,7 @@ def test_ptq_calibrate_pixart_reproduces_reference_quant_params(dev, ops, tmp_pa
     assert torch.equal(q2(x.to(dev), t.to(dev), y.to(dev), mask=mask.to(dev)), out)
 
 
-def test_tiny_pixart_dpm_solver_trajectory(dev, ops):
+def test_tiny_pixart_dpm_solver_trajectory(dev, ops, parity):
     """The t2i sampling loop (quant_txt2img.py:130-153): DPM-Solver++ 2M, cfg 4.5, one batched (uncond | cond)
     forward of the quantized PixArt-MS per step, vs the trajectory the reference's solver produced."""
     import viditq_amd  # noqa
@@ -460,7 +464,8 @@ def test_tiny_pixart_dpm_solver_trajectory(dev, ops):
                         model_kwargs=dict(data_info=None, mask=g["mask"][:1].to(dev)))
     out = solver.sample(g["dpm_z"].to(dev), steps=5, order=2, skip_type="time_uniform", method="multistep")
     # 5 guided steps (cfg 4.5 amplifies the cond/uncond difference) on fp16 activations and fp16 timesteps
-    assert rel_l2(out.cpu().float(), g["dpm_final"]) < 2e-2
+    parity["tiny_pixart_ms/dpm_final"] = {"vs_ref_fp32": rel_l2(out.cpu().float(), g["dpm_final"])}
+    assert rel_l2(out.cpu().float(), g["dpm_final"]) < 2.5e-3     # recorded 1.9e-3
 
 
 def test_prompt_cache_is_exact(dev, ops):

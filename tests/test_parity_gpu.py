@@ -152,14 +152,16 @@ def test_static_activation_plans_match_reference(dev, ops, parity, tag, per_grou
     assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
     cond = qnn(x, torch.tensor([300], device=dev), y[:1], mask=mask).cpu()
     e = _rec(parity, "tiny_stdit_static/%s_cond_t300" % tag, cond, g[tag + "_cond_t300"])
-    assert e["vs_ref_fp32"] < 3e-3, e
+    assert e["vs_ref_fp32"] < 2.0e-3, e          # recorded 1.59e-3 (tw) / 1.32e-3 (tk)
     if tag == "tw":
-        # a dynamic grid silently substituted for the calibrated one would land ~1e-2 away
+        # a dynamic grid silently substituted for the calibrated one is a DIFFERENT result
+        # (measured: 2.6e-3 from the reference against 1.6e-3 on the calibrated grid)
         wq_d, aq_d = _cfgs(8, mixed_precision=[4, 6, 8])
         qd = _stdit(g, dev, wq_d, aq_d, cfg_split=False)
         _load_qp(qd, {k: v for k, v in quant_params_of(g, "qp_tw").items() if k.endswith("weight_quantizer")})
         dyn = qd(torch.cat([x, x]), t, y, mask=mask).cpu()
-        assert rel_l2(dyn, g["tw_joint_t721"]) > 2 * e["vs_ref_fp32"]
+        assert rel_l2(dyn, joint) > 1e-3
+        assert rel_l2(dyn, g["tw_joint_t721"]) > 1.3 * rel_l2(joint, g["tw_joint_t721"])
 
 
 def test_ptqd_ddim_with_nonzero_k_matches_reference(dev, ops, parity):
@@ -177,7 +179,7 @@ def test_ptqd_ddim_with_nonzero_k_matches_reference(dev, ops, parity):
     e = _rec(parity, "tiny_stdit_static/tw_ptqd_ddim_final", out, g["tw_ptqd_ddim_final"], g["tw_ptqd_ddim_final_ref_fp16"])
     assert e["vs_ref_fp32"] < 2.0 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
     out0 = sch.ddim_sample_loop(qnn, g["ddim_z"].to(dev), dict(y=y, mask=mask)).cpu()      # k = 0 is a different result
-    assert rel_l2(out0, g["tw_ptqd_ddim_final"]) > 10 * e["vs_ref_fp32"]
+    assert rel_l2(out0, g["tw_ptqd_ddim_final"]) > 3 * e["vs_ref_fp32"]                  # 3.6e-3 vs 7.8e-4
 
 
 @pytest.mark.parametrize("tag,per_group", [("tw", False), ("tk", "token")])
@@ -207,7 +209,9 @@ def test_ptq_calibrate_static_activation_grids(dev, ops, tag, per_group):
         # extreme element plus upstream code flips
         assert torch.allclose(a.reshape(b.shape), b, rtol=2e-2, atol=1e-7), (name, float((a.reshape(b.shape) - b).abs().max()))
         za, zb = bufs["zero_point"].float().cpu(), ref[name]["zero_point"].float()
-        assert (za.reshape(zb.shape) - zb).abs().max() <= 3, name
+        # round(-min / delta): a few codes normally; under the eps fill (delta = 1e-6) the zero point is ~5e4 and moves
+        # with the fp16 rounding of the minimum
+        assert ((za.reshape(zb.shape) - zb).abs() <= torch.clamp(1e-3 * zb.abs(), min=3)).all(), name
         n += 1
     assert n == 2 * 13
     if per_group == "token":
@@ -248,8 +252,8 @@ def test_pixart_alpha_net_matches_reference(dev, ops, parity):
     assert rel_l2(qnn(x, t, y, mask=mask).cpu().float(), g["fp"]) < 3e-3          # FP model, fp16 storage
     _load_qp(qnn, quant_params_of(g, "qp"))
     assert all(b.fused_ok() for b in qnn.model.blocks)
-    e = _rec(parity, "tiny_pixart_alpha/w8a8", qnn(x, t, y, mask=mask).cpu().float(), g["w8a8"])
-    assert e["vs_ref_fp32"] < 5e-3, e
+    e = _rec(parity, "tiny_pixart_alpha/w8a8", qnn(x, t, y, mask=mask).cpu().float(), g["w8a8"], g["w8a8_ref_fp16"])
+    assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
     out1 = qnn(x[:1], t[:1], y[:1], mask=mask[:1]).cpu().float()
     e = _rec(parity, "tiny_pixart_alpha/w8a8_b1", out1, g["w8a8_b1"], g["w8a8_b1_ref_fp16"])
     assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e
@@ -258,14 +262,14 @@ def test_pixart_alpha_net_matches_reference(dev, ops, parity):
                         model_kwargs=dict(data_info=None, mask=g["mask"][:1].to(dev)))
     out = solver.sample(g["dpm_z"].to(dev), steps=4, order=2, skip_type="time_uniform", method="multistep")
     e = _rec(parity, "tiny_pixart_alpha/dpm_final", out.cpu().float(), g["dpm_final"])
-    assert e["vs_ref_fp32"] < 2e-2, e
+    assert e["vs_ref_fp32"] < 3.4e-3, e           # recorded 2.7e-3: 4 guided steps (cfg 4.5) of this more sensitive tiny net
     # static tensor-wise plan (alpha/w8a8_naive.yaml) on the fused route
     wq, aq = _cfgs(8, dynamic=False, per_group=False, T=1, S=64)
     qn = _pixart("PixArt", g, dev, wq, aq)
     _load_qp(qn, quant_params_of(g, "qp_naive"))
     assert all(b.fused_ok() for b in qn.model.blocks)
-    e = _rec(parity, "tiny_pixart_alpha/naive", qn(x, t, y, mask=mask).cpu().float(), g["naive"])
-    assert e["vs_ref_fp32"] < 5e-3, e
+    e = _rec(parity, "tiny_pixart_alpha/naive", qn(x, t, y, mask=mask).cpu().float(), g["naive"], g["naive_ref_fp16"])
+    assert e["vs_ref_fp32"] < 1.25 * e["ref_fp16_vs_ref_fp32"] + 1e-4, e       # recorded 5.3e-3; the reference's fp16 mode: 6.3e-3
 
 
 def test_pixart_w4a8_running_smooth_quant_statistic(dev, ops, parity):
@@ -288,11 +292,11 @@ def test_pixart_w4a8_running_smooth_quant_statistic(dev, ops, parity):
         a, b = fc2.act_quantizer.act_scale.cpu().float(), g["act_scale_after_call%d" % j]
         assert torch.allclose(a.reshape(b.shape), b, rtol=2e-2, atol=1e-4)             # max|x| of fp16 activations
         e = _rec(parity, "tiny_pixart_w4a8/call%d_t%d" % (j, tv), out, g["w4a8_call%d_t%d" % (j, tv)])
-        assert e["vs_ref_fp32"] < 1e-2, e                                             # 4-bit weights (cf. W4A8 STDiT)
+        assert e["vs_ref_fp32"] < 5.2e-3, e           # recorded 4.0 - 4.2e-3 (4-bit weights, quantized final layer)
     qnn.load_bitwidth_config(qnn, {"model.blocks.0.attn.qkv": 8, "model.blocks.1.mlp.fc1": 6}, "weight")
     out = qnn(x, torch.tensor([820, 820], device=dev), y, mask=mask).cpu().float()
     e = _rec(parity, "tiny_pixart_w4a8/mp_call3_t820", out, g["w4a8_mp_call3_t820"])
-    assert e["vs_ref_fp32"] < 1e-2, e
+    assert e["vs_ref_fp32"] < 5.0e-3, e               # recorded 3.9e-3
     assert qnn.model.blocks[0].attn.qkv.packed_weight(0).n_bits == 8
 
 
@@ -349,9 +353,10 @@ def test_full_size_stdit_block_matches_oracle(dev, ops, parity, plan):
         eb = _rec(parity, "full_size/stdit_block_%s_t%d" % (plan, tv), blocks[0].cpu().float().reshape(1, 16384, 1152),
                   rblocks[0], tokens=16384, C=1152)
         eo = _rec(parity, "full_size/stdit_depth1_model_%s_t%d" % (plan, tv), out, ref)
-        # ~20 kernels with fp16 storage between them; the reference's own fp16 mode is 1.0e-3 from fp32 on a block
-        assert eb["vs_ref_fp32"] < (2e-3 if plan == "w8a8" else 4e-3), eb
-        assert eo["vs_ref_fp32"] < (3e-3 if plan == "w8a8" else 6e-3), eo
+        # north_star's 1e-3 HOLDS on the full-size block: recorded 5.7e-4 (W8A8) / 5.8e-4 (W4A8), depth-1 model 8.0e-4
+        # (profiles/r02_parity.json); asserted at 1.25 x the recorded values
+        assert eb["vs_ref_fp32"] < 7.3e-4, eb
+        assert eo["vs_ref_fp32"] < 1.0e-3, eo
     assert qnn.check_status() == 0
 
 
@@ -394,7 +399,7 @@ def test_full_size_pixart_block_n4096_lp300_matches_oracle(dev, ops, parity):
     ref = pr.pixart_forward(sd, dict(H=16, depth=1, patch=2, out_ch=8), x.cpu().half().float(), t.cpu(), y.cpu().float(),
                             mask, spec, pe)
     e = _rec(parity, "full_size/pixart_depth1_model_w4a8_n4096_lp300_b2", out, ref, tokens=4096, prompt_tokens=[300, 143])
-    assert e["vs_ref_fp32"] < 8e-3, e            # 4-bit weights + quantized final layer (cf. tiny W4A8: 3e-3 in fp16 mode)
+    assert e["vs_ref_fp32"] < 4.5e-3, e          # recorded 3.5e-3: 4-bit weights + a quantized final layer (t2i FP list)
     assert qnn.check_status() == 0
 
 

@@ -18,55 +18,136 @@ def _free_port():
     return p
 
 
-def _tiny_qnn():
-    import viditq_amd  # noqa
-    from viditq_amd.config import to_config
-    from viditq_amd.qdiff.models import QuantModel
-    from viditq_amd.t2v import STDiT
-    torch.manual_seed(0)
-    m = STDiT(input_size=(4, 8, 8), depth=1, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
-    wq = to_config(dict(n_bits=8, per_group="channel", channel_dim=0, scale_method="min_max", round_mode="nearest"))
-    aq = to_config(dict(n_bits=8, per_group="token", scale_method="min_max", round_mode="nearest_ste",
-                        running_stat=False, dynamic=True, sym=False, n_spatial_token=16, n_temporal_token=4,
-                        n_prompt=12, smooth_quant=dict(enable=False)))
-    qnn = QuantModel(m, wq, aq)
-    qnn.set_module_name_for_quantizer(qnn.model)
+TINY = dict(input_size=(4, 8, 8), depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32)
+
+
+def _install_cpu_ops(counters):
+    """The ONLY mocked boundary: the weight-side HIP entry points (vq_weight_minmax, vq_pack_weight, the
+    calibrated-grid form of vq_fakequant_act), restated with the oracle on CPU tensors - they need a GPU.  Everything above them - quantizer classes, QuantLayer caches,
+    QuantModel state, synth / shard control flow, the arena, the collectives - is the product code."""
+    from oracle import fakequant as fq
+    from viditq_amd import ops
+
+    def weight_minmax(W, n_bits, s=None, force_eps=False, status=None):
+        Wf = W.float() if s is None else W.float() * s.reshape(1, -1)
+        d, z, eps = fq.minmax_params(Wf.reshape(Wf.shape[0], -1), n_bits)
+        if eps and status is not None:
+            status |= 1
+        return d, z
+
+    def pack_weight(W, delta, zp, n_bits, s=None, out=None):
+        counters["pack"] = counters.get("pack", 0) + 1
+        N, K = W.shape
+        Kp = ops.pad128(K)
+        Wf = W.float() if s is None else W.float() * s.reshape(1, -1)
+        codes = fq.quant_codes(Wf, delta.reshape(-1, 1), zp.reshape(-1, 1), n_bits)
+        cx = 128 if n_bits == 8 else 0
+        if out is None:
+            out = [torch.empty(sh, dtype=dt) for sh, dt in ops.packed_shapes(N, K, n_bits)]
+        wq, sw, zw, cs = out
+        if n_bits <= 4:
+            c = torch.zeros(N, Kp, dtype=torch.uint8)
+            c[:, :K] = codes.to(torch.uint8)
+            c4 = c.reshape(N, Kp // 8, 2, 4)                      # stand-in nibble order (layout is the kernel's business)
+            wq.copy_((c4[:, :, 0] | (c4[:, :, 1] << 4)).reshape(N, Kp // 2))
+        else:
+            wq.zero_()
+            wq[:, :K] = (codes - cx).to(torch.int8)
+        sw.copy_(delta.reshape(-1))
+        zw.copy_((zp.reshape(-1) - cx).to(torch.int32))
+        cs.copy_(((codes - cx).sum(dim=1) - K * (zp.reshape(-1) - cx)).to(torch.int32))
+        return ops.PackedWeight(wq, sw, zw, cs, N, K, Kp, n_bits)
+
+    def new_status(device):
+        return torch.zeros(1, dtype=torch.int32)
+
+    def fakequant_act(x, n_bits=8, delta=None, zp=None, status=None, want_codes=False):
+        assert delta is not None, "only the calibrated-grid form is used on weights"
+        n = delta.numel()
+        d = delta.reshape(1, n, 1) if n > 1 else delta.reshape(1, 1, 1)
+        z = zp.reshape(1, n, 1) if n > 1 else zp.reshape(1, 1, 1)
+        codes = fq.quant_codes(x.float(), d, z, n_bits)
+        return fq.dequant(codes, d, z).half(), None, delta, zp
+
+    ops.weight_minmax, ops.pack_weight, ops.new_status, ops.fakequant_act = weight_minmax, pack_weight, new_status, fakequant_act
+
+
+def _fake_calibration(qnn, cfg, fp_layers=None, seed=7):
+    """Stand-in for synth.calibrate_synthetic on CPU (it samples an FP DDIM trajectory through the HIP attention
+    kernels): the same END STATE - a momentum act-scale statistic per layer and time-range, weight grids of W*s for
+    every range from the product's own WeightQuantizer - from seeded random statistics."""
+    g = torch.Generator().manual_seed(seed)
+    qnn.set_smooth_quant(smooth_quant=True, smooth_quant_running_stat=False)
+    qnn.set_layer_smooth_quant(model=qnn, module_name_list=list(fp_layers), smooth_quant=False,
+                               smooth_quant_running_stat=False)
+    for name, layer in qnn.quant_layers():
+        if not layer.smooth_quant:
+            layer.weight_quantizer(layer.weight.detach().half())
+            continue
+        K = layer.weight.shape[1]
+        layer.act_quantizer.act_scale = torch.rand(len(layer.timerange), 1, K, generator=g) + 0.5
+        wq = layer.weight_quantizer
+        wq.timestep_wise, wq.n_timestep = True, len(layer.timerange)
+        for r in range(len(layer.timerange)):
+            wq.cur_timestep_id = r
+            s = layer.channel_wise_scale(r, layer._alpha_of(r)).reshape(-1)
+            for nb in wq.mixed_precision:
+                wq.init_quant_params(layer.weight.detach().half(), wq.per_group, n_bits=nb, smooth=s)
+        wq.delta, wq.zero_point = wq.delta_list[wq.bit_idx, 0], wq.zero_point_list[wq.bit_idx, 0]
     return qnn
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, plan):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from viditq_amd import ops, shard
-        qnn = _tiny_qnn()
-        layers = dict(qnn.quant_layers())
-        g = torch.Generator().manual_seed(123)
-        if rank == 0:   # fabricate the state rank 0 would hold after weight PTQ + packing
-            for name, layer in layers.items():
-                N, K = layer.weight.shape
-                wq = layer.weight_quantizer
-                wq.delta_list = torch.rand(1, 1, N, 1, generator=g)
-                wq.zero_point_list = torch.randint(0, 255, (1, 1, N, 1), generator=g).float()
-                wq.delta, wq.zero_point = wq.delta_list[0, 0], wq.zero_point_list[0, 0]
-                Kp = ops.pad128(K)
-                pw = ops.PackedWeight(torch.randint(-128, 127, (N, Kp), generator=g, dtype=torch.int8),
-                                      torch.rand(N, generator=g), torch.randint(-128, 127, (N,), generator=g, dtype=torch.int32),
-                                      torch.randint(-9999, 9999, (N,), generator=g, dtype=torch.int32), N, K, Kp, 8)
-                layer.install_packed(0, pw)
-        nbytes = shard.broadcast_quant_state(qnn, rank, src=0)
-        # every rank now holds identical grids and packed weights: checksum of checksums
+        import viditq_amd  # noqa
+        from viditq_amd import shard, synth
+        from viditq_amd.config import loads_yaml
+        from viditq_amd.t2v import STDiT
+        counters = {}
+        _install_cpu_ops(counters)
+        synth.calibrate_synthetic = _fake_calibration
+        torch.manual_seed(0)                                     # every rank builds the same fp16 model
+        m = STDiT(dtype=torch.float16, **TINY)
+        synth.redraw_zero_init(m, 1)
+        m = m.half().eval()
+        cfg = loads_yaml(synth.W8A8_DYNAMIC if plan == "w8a8" else synth.W4A8_TIMESTEP_AWARE)
+        cfg.quant.activation.quantizer["n_spatial_token"], cfg.quant.activation.quantizer["n_temporal_token"] = 16, 4
+        qnn = shard.quantize_and_distribute(m, cfg, rank, world)              # the REAL control flow, both branches
+        n_ranges = 1 if plan == "w8a8" else 2
+        bits = 8 if plan == "w8a8" else 4
+        hot = [(n, l) for n, l in qnn.quant_layers() if n.startswith("blocks.")]
+        assert len(hot) == 2 * 13
+        if rank != 0:
+            assert counters.get("pack", 0) == 0                  # nothing was packed here: everything arrived
+        packs_before = counters.get("pack", 0)
         acc = torch.zeros(1, dtype=torch.float64)
-        for name, layer in sorted(layers.items()):
-            pw = layer._packed[(0, 8)][0]
-            assert layer._packed[(0, 8)][1] is layer.weight_quantizer.delta
-            assert pw.wq.dtype == torch.int8 and pw.N == layer.weight.shape[0]
-            acc += pw.wq.double().sum() + pw.sw.double().sum() + pw.zw.double().sum() + pw.cs.double().sum()
-            acc += layer.weight_quantizer.delta_list.double().sum()
+        arena = qnn._packed_arena
+        lo, hi = arena.data_ptr(), arena.data_ptr() + arena.numel()
+        for name, layer in sorted(hot):
+            assert layer.get_quant_state() == (True, True) and layer.int_route_ok()
+            assert layer.weight_quantizer.init_done and layer.act_quantizer.init_done
+            for r in range(n_ranges):
+                layer.cur_timestep_id = 0 if r == 0 else 600
+                rr, alpha = layer._range_and_alpha()
+                assert rr == r
+                pw = layer.packed_weight(rr, layer.smooth_vector(rr, alpha))   # what the hot loop asks for
+                assert pw.n_bits == bits and pw.wq.dtype == (torch.int8 if bits == 8 else torch.uint8)
+                for t_ in pw.tensors():                          # zero-copy: views of the ONE broadcast buffer, on rank 0 too
+                    assert lo <= t_.data_ptr() < hi
+                acc += sum(t_.double().sum() for t_ in pw.tensors())
+            acc += layer.weight_quantizer.delta_list.double().sum() + layer.weight_quantizer.zero_point_list.double().sum()
+            if plan != "w8a8":
+                acc += layer.act_quantizer.act_scale.double().sum()
+        assert counters.get("pack", 0) == packs_before           # ... and asking again packs nothing, on any rank
+        for n, l in qnn.quant_layers():                          # the FP list stays FP everywhere
+            if not n.startswith("blocks."):
+                assert l.get_quant_state() == (False, False)
         both = [torch.zeros_like(acc) for _ in range(world)]
         dist.all_gather(both, acc)
-        assert torch.equal(both[0], both[1]) and nbytes > 0
+        assert torch.equal(both[0], both[1]) and float(acc) != 0.0
         # partition + gather: 5 prompts over 2 ranks, round robin
         n_prompts = 5
         mine = shard.prompts_of_rank(n_prompts, rank, world)
@@ -99,10 +180,15 @@ def test_blob_roundtrip_is_zero_copy_and_aligned():
 
 
 @pytest.mark.timeout(300)
-def test_broadcast_and_gather_world2_gloo():
+@pytest.mark.parametrize("plan", ["w8a8", "w4a8"])
+def test_quantize_and_distribute_world2_gloo(plan):
+    """shard.quantize_and_distribute as bench.py calls it, on two gloo ranks: rank 0 runs weight PTQ (dynamic plan) or
+    calibration (smooth-quant plan, two time-ranges), packs INTO the arena and broadcasts it once; rank 1 only sets the
+    inference state and installs views of what arrived.  Checks: both control-flow branches on both ranks, identical
+    grids / packed weights / act scales (checksum of checksums), zero packing work off rank 0, zero-copy views."""
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, plan), nprocs=world, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}

@@ -217,9 +217,17 @@ def weight_minmax(W: torch.Tensor, n_bits: int, s: Optional[torch.Tensor] = None
     return delta, zp
 
 
+def packed_shapes(N: int, K: int, n_bits: int):
+    """(shape, dtype) of the four tensors of a PackedWeight [N, K] at ``n_bits``: codes, sw, zw, cs."""
+    Kp = pad128(K)
+    wq = ((N, Kp // 2), torch.uint8) if n_bits <= 4 else ((N, Kp), torch.int8)
+    return [wq, ((N,), torch.float32), ((N,), torch.int32), ((N,), torch.int32)]
+
+
 def pack_weight(W: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, n_bits: int,
-                s: Optional[torch.Tensor] = None) -> PackedWeight:
-    """Quantize W*s on the (delta, zp) grid and pack for the int8 MFMA GEMM."""
+                s: Optional[torch.Tensor] = None, out: Optional[Sequence[torch.Tensor]] = None) -> PackedWeight:
+    """Quantize W*s on the (delta, zp) grid and pack for the int8 MFMA GEMM.  ``out`` = (wq, sw, zw, cs) pre-allocated
+    with :func:`packed_shapes` (e.g. views of one broadcast arena, shard.py) instead of fresh tensors."""
     _req(W, torch.float16, "W")
     N, K = W.shape
     Kp = pad128(K)
@@ -227,13 +235,17 @@ def pack_weight(W: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, n_bits: 
     d = _req(delta.reshape(-1).contiguous(), torch.float32, "delta")
     z = _req(zp.reshape(-1).contiguous(), torch.float32, "zp")
     assert d.numel() == N and z.numel() == N
-    if n_bits <= 4:
-        wq = torch.empty((N, Kp // 2), dtype=torch.uint8, device=dev)
+    if out is not None:
+        wq, sw, zw, cs = out
+        for t_, (shape, dt) in zip(out, packed_shapes(N, K, n_bits)):
+            if tuple(t_.shape) != tuple(shape) or t_.dtype != dt or not t_.is_contiguous() or t_.device != dev:
+                raise VQError("pack_weight: out tensors must match packed_shapes() on the weight's device")
     else:
-        wq = torch.empty((N, Kp), dtype=torch.int8, device=dev)
-    sw = torch.empty(N, dtype=torch.float32, device=dev)
-    zw = torch.empty(N, dtype=torch.int32, device=dev)
-    cs = torch.empty(N, dtype=torch.int32, device=dev)
+        (wqs, wqd), _, _, _ = packed_shapes(N, K, n_bits)
+        wq = torch.empty(wqs, dtype=wqd, device=dev)
+        sw = torch.empty(N, dtype=torch.float32, device=dev)
+        zw = torch.empty(N, dtype=torch.int32, device=dev)
+        cs = torch.empty(N, dtype=torch.int32, device=dev)
     if s is not None:
         _req(s, torch.float32, "s")
     check(_L().vq_pack_weight(_p(W), _p(s), _p(d), _p(z), _p(wq), _p(sw), _p(zw), _p(cs), N, K, Kp, n_bits,

@@ -171,7 +171,7 @@ class QuantLayer(nn.Module):
         a = getattr(self.act_quantizer, "act_scale", None)
         return None if a is None else (a.data_ptr(), a._version)
 
-    def packed_weight(self, r: int = 0, s: Optional[torch.Tensor] = None) -> ops.PackedWeight:
+    def packed_weight(self, r: int = 0, s: Optional[torch.Tensor] = None, out=None) -> ops.PackedWeight:
         """int8/int4 codes of W*s_r on the grid the reference uses: ALWAYS ``weight_quantizer.delta``
         = delta_list[bit_idx at PTQ, range 0] (base_quantizer.py:126), clamped at the
         CURRENT n_bits.  An entry is valid for the grid, the weight version AND the smoothing vector it was
@@ -190,7 +190,7 @@ class QuantLayer(nn.Module):
         if W.dtype != torch.float16:
             W = W.half()
         pw = ops.pack_weight(W.contiguous(), wq.delta.reshape(-1).float(), wq.zero_point.reshape(-1).float(),
-                             wq.n_bits, s=None if s is None else s.reshape(-1).float().contiguous())
+                             wq.n_bits, s=None if s is None else s.reshape(-1).float().contiguous(), out=out)
         self._packed[key] = (pw, wq.delta, self.weight._version, s, self._act_scale_version())
         return pw
 

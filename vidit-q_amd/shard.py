@@ -60,8 +60,8 @@ def unpack_blob(meta: list, blob: torch.Tensor) -> Dict[str, torch.Tensor]:
 
 
 # --------------------------------------------------------------------------- what travels
-def _export_quant_state(qnn: QuantModel) -> List[Tuple[str, torch.Tensor]]:
-    """Weight-quantizer grids + every packed weight (all time-ranges present) of every QuantLayer."""
+def _small_state(qnn: QuantModel) -> List[Tuple[str, torch.Tensor]]:
+    """Weight-quantizer grids and smooth-quant statistics of every QuantLayer (a few MB in total)."""
     items = []
     for name, layer in qnn.quant_layers():
         wq = layer.weight_quantizer
@@ -72,12 +72,62 @@ def _export_quant_state(qnn: QuantModel) -> List[Tuple[str, torch.Tensor]]:
         aq = layer.act_quantizer
         if getattr(aq, "act_scale", None) is not None:
             items.append(("%s|aq|act_scale" % name, aq.act_scale))
-        for key, ent in layer._packed.items():
-            if isinstance(key[0], int):
-                pw = ent[0]
-                for f in ("wq", "sw", "zw", "cs"):
-                    items.append(("%s|pw|%d|%d|%s" % (name, key[0], key[1], f), getattr(pw, f)))
     return items
+
+
+def _pack_jobs(qnn: QuantModel):
+    """(layer name, layer, time-range id, representative timestep) of every packed weight the hot loop will ask for."""
+    jobs = []
+    for name, layer in qnn.quant_layers():
+        if layer.weight_quant and layer.act_quant and layer._can_pack():
+            n_r = len(layer.timerange) if getattr(layer, "smooth_quant", False) else 1
+            for r in range(n_r):
+                jobs.append((name, layer, r, layer.timerange[r][0] if n_r > 1 else None))
+    return jobs
+
+
+def _pack_one(layer: QuantLayer, r: int, t_id, out=None):
+    saved = layer.cur_timestep_id
+    if t_id is not None:
+        layer.cur_timestep_id = t_id
+    rr, alpha = layer._range_and_alpha()
+    pw = layer.packed_weight(rr, layer.smooth_vector(rr, alpha), out=out)
+    layer.cur_timestep_id = saved
+    return pw
+
+
+def prepack(qnn: QuantModel):
+    """Pack every quantized Linear for every time-range so nothing is packed inside the loop."""
+    for _, layer, r, t_id in _pack_jobs(qnn):
+        _pack_one(layer, r, t_id)
+
+
+def prepack_into_arena(qnn: QuantModel):
+    """Like :func:`prepack`, but the packed codes and per-channel terms are written straight into ONE flat byte
+    buffer - the buffer that is then broadcast as is.  Rank 0 therefore never holds a second copy of the ~0.75 GB of
+    packed weights (W8A8 STDiT-XL/2); the small state (grids, act scales) is copied behind them.  Returns
+    (meta, arena)."""
+    from . import ops
+    dev = next(qnn.model.parameters()).device
+    jobs = _pack_jobs(qnn)
+    specs = []                                            # (key, shape, dtype) in arena order
+    for name, layer, r, _ in jobs:
+        N, K = layer.weight.shape
+        nb = layer.weight_quantizer.n_bits
+        for f, (shape, dt) in zip(("wq", "sw", "zw", "cs"), ops.packed_shapes(N, K, nb)):
+            specs.append(("%s|pw|%d|%d|%s" % (name, r, nb, f), tuple(shape), dt))
+    small = _small_state(qnn)
+    specs += [(k, tuple(v.shape), v.dtype) for k, v in small]
+    meta, total = _layout([(k, torch.empty(shape, dtype=dt, device="meta")) for k, shape, dt in specs])
+    arena = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
+    views = unpack_blob(meta, arena)
+    for name, layer, r, t_id in jobs:
+        nb = layer.weight_quantizer.n_bits
+        out = [views["%s|pw|%d|%d|%s" % (name, r, nb, f)] for f in ("wq", "sw", "zw", "cs")]
+        _pack_one(layer, r, t_id, out=out)
+    for k, v in small:
+        views[k].copy_(v)
+    return meta, arena
 
 
 def _install_quant_state(qnn: QuantModel, tensors: Dict[str, torch.Tensor]):
@@ -100,26 +150,13 @@ def _install_quant_state(qnn: QuantModel, tensors: Dict[str, torch.Tensor]):
         layer.install_packed(r, pw)
 
 
-def prepack(qnn: QuantModel):
-    """Pack every quantized Linear for every time-range so nothing is packed inside the loop."""
-    for _, layer in qnn.quant_layers():
-        if layer.weight_quant and layer.act_quant and layer._can_pack():
-            n_r = len(layer.timerange) if getattr(layer, "smooth_quant", False) else 1
-            saved = layer.cur_timestep_id
-            for r in range(n_r):
-                if n_r > 1:
-                    layer.cur_timestep_id = layer.timerange[r][0]
-                rr, alpha = layer._range_and_alpha()
-                layer.packed_weight(rr, layer.smooth_vector(rr, alpha))
-            layer.cur_timestep_id = saved
-
-
-def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None):
-    """One flat-buffer broadcast of grids + packed weights from ``src`` to all ranks."""
+def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None, packed=None):
+    """One flat-buffer broadcast of grids + packed weights from ``src`` to all ranks.  ``packed`` = the (meta, arena)
+    of :func:`prepack_into_arena` on ``src`` (packed in place, no copy); without it ``src`` packs now."""
     import torch.distributed as dist
     dev = next(qnn.model.parameters()).device
     if rank == src:
-        meta, blob = pack_blob(_export_quant_state(qnn), dev)
+        meta, blob = packed if packed is not None else prepack_into_arena(qnn)
         obj = [meta, int(blob.numel())]
     else:
         obj = [None, None]
@@ -130,6 +167,7 @@ def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None):
     dist.broadcast(blob, src=src, group=group)
     if rank != src:
         _install_quant_state(qnn, unpack_blob(meta, blob))
+    qnn._packed_arena = blob        # the views installed above / packed in place live in this buffer
     return int(nbytes)
 
 
@@ -142,6 +180,7 @@ def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.R
         return qnn
     qnn = synth.wrap_model(model, cfg, fp_layers)
     smooth = synth.uses_smooth_quant(cfg)
+    packed = None
     if rank == 0:
         if smooth:
             synth.calibrate_synthetic(qnn, cfg, fp_layers)
@@ -149,14 +188,14 @@ def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.R
         else:
             synth.init_weight_quantizers(qnn)
             qnn.set_quant_state(True, True)
-        prepack(qnn)
+        packed = prepack_into_arena(qnn)      # packed IN the buffer that is broadcast: no second copy on rank 0
     elif smooth:
         synth.set_inference_state(qnn, cfg, fp_layers)
     else:
         qnn.set_quant_init_done("weight")
         qnn.set_quant_init_done("activation")
         qnn.set_quant_state(True, True)
-    broadcast_quant_state(qnn, rank, 0)
+    broadcast_quant_state(qnn, rank, 0, packed=packed)
     return qnn
 
 
