@@ -45,6 +45,11 @@ extern "C" {
 #define VQ_ST_EPSFILL 1  /* some token had delta < 1e-6: the reference would fill
                             EVERY delta with 1e-6 (base_quantizer.py:220-222) */
 
+/* GEMM kernel choice: VQ_GEMM_DEFAULT lets the library choose per shape; an explicit number pins one kernel
+ * (11 = full-line LDS-DMA ring, one 256 x 288 tile per 8-wave workgroup).  Retired generations and profiling
+ * ablations are not part of this library (tools/lab). */
+#define VQ_GEMM_DEFAULT (-1)
+
 /* GEMM epilogues */
 #define VQ_EPI_NONE 0        /* out = y                                        */
 #define VQ_EPI_GELU 1        /* out = gelu_tanh(y)      (mlp.fc1 -> act)       */
@@ -209,14 +214,6 @@ int vq_adaln_table(const void* table, const void* t0, float* mod, int B, int J, 
 int vq_cfg_ddim_step(const float* cond, const float* uncond, const float* x, float* x_out,
                      int n, int C, int inner, float cfg, float one_plus_k,
                      float A, float Bc, float abar_prev, void* stream);
-
-/* MFMA lane-layout probe (test infrastructure of the library itself): fills
- * out[32*32] int32 with A(32x32,i8) * B^T using one wave; a,b are [32,32] int8. */
-int vq_probe_mfma_i8(const int8_t* a, const int8_t* b, int32_t* out, void* stream);
-
-/* MFMA / LDS / barrier issue-rate micro-benchmark (library self-test, tools/mfma_rate.py). */
-int vq_probe_mfma_rate(int mode, int iters, int blocks, int* out, void* stream);
-int vq_probe_stage_rate(int mode, const void* src, int stride, int iters, int blocks, int* out, void* stream);
 
 #ifdef __cplusplus
 }

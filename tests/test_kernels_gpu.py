@@ -24,14 +24,9 @@ def h16(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).half()
 
 
-# ----------------------------------------------------------------------------- MFMA layout
-def test_mfma_i8_layout_probe(ops, dev):
-    g = torch.Generator().manual_seed(1)
-    a = torch.randint(-128, 128, (32, 32), generator=g, dtype=torch.int8)
-    b = torch.randint(-128, 128, (32, 32), generator=g, dtype=torch.int8)  # asymmetric on purpose
-    out = ops.probe_mfma_i8(a.to(dev), b.to(dev)).cpu()
-    ref = a.int() @ b.int().t()
-    assert torch.equal(out, ref)
+# GEMM kernels of the product library: -1 = the library's own choice per shape, explicit numbers pin one kernel
+# (retired generations are measured from tools/lab, not tested here)
+GEMM_VARIANTS = [-1, 11]
 
 
 # ----------------------------------------------------------------------------- rowquant
@@ -138,7 +133,7 @@ def _oracle_linear(x, W, b, w_bits, a_bits, s=None):
                            smooth=None if s is None else s.reshape(1, -1))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 20, 21])
+@pytest.mark.parametrize("variant", GEMM_VARIANTS)
 @pytest.mark.parametrize("M,N,K", [(64, 48, 96), (300, 292, 128), (512, 576, 1152), (130, 1152, 4608)])
 def test_gemm_w8a8_vs_oracle(ops, dev, variant, M, N, K):
     x = h16(1, M, K, scale=1.5, seed=M + K)
@@ -152,29 +147,6 @@ def test_gemm_w8a8_vs_oracle(ops, dev, variant, M, N, K):
     # fp16 output rounding only: 2^-11 relative per element
     assert rel_l2(out, ref) < 5e-4
     assert (out - ref).abs().max() <= 2e-3 * ref.abs().max()
-
-
-@pytest.mark.parametrize("M,N,K,epi", [(16384, 3456, 1152, "none"), (16384, 4608, 1152, "gelu"), (16000, 3400, 256, "none"),
-                                       (9000, 2600, 384, "gelu")])
-def test_gemm_persistent_equals_one_tile_per_workgroup(ops, dev, M, N, K, epi):
-    """Variant 14 walks several tiles per workgroup (more tiles than CUs) and prefetches the next tile's first stage
-    under the epilogue; its results must be bit-identical to variant 11 (checked against the oracle above), ragged
-    edge tiles included; and a row sample is compared with the oracle directly."""
-    x = h16(1, M, K, scale=1.5, seed=M + K)
-    W = h16(N, K, scale=0.04, seed=N)
-    b = h16(N, scale=0.1, seed=5).float()
-    qa = ops.rowquant(x.to(dev))
-    d, z = ops.weight_minmax(W.to(dev), 8)
-    pw = ops.pack_weight(W.to(dev), d, z, 8)
-    e = ops.EPI_GELU if epi == "gelu" else ops.EPI_NONE
-    o11 = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=e, variant=11)
-    o14 = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=e, variant=14)
-    assert torch.equal(o11, o14)
-    rows = torch.arange(0, M, max(1, M // 48))[:48]                 # rows from every part of the tile walk
-    ref = _oracle_linear(x[:, rows], W, b, 8, 8)[0]
-    if epi == "gelu":
-        ref = torch.nn.functional.gelu(ref, approximate="tanh")
-    assert rel_l2(o14[rows].cpu().float(), ref) < 1e-3
 
 
 @pytest.mark.parametrize("w_bits", [4, 6])
@@ -191,11 +163,11 @@ def test_gemm_low_bit_weights(ops, dev, w_bits):
     assert rel_l2(out, ref) < 5e-4
 
 
-@pytest.mark.parametrize("variant", [0, 10, 11, 12, 13, 15])
+@pytest.mark.parametrize("variant", GEMM_VARIANTS)
 @pytest.mark.parametrize("M,N,K", [(64, 48, 96), (300, 292, 128), (512, 576, 1152), (130, 1152, 4608)])
 def test_gemm_w4a8_vs_oracle(ops, dev, variant, M, N, K):
-    """Nibble-packed weights through the register-staged kernel (0) and the LDS-DMA ring (10: packed
-    rows are DMA-ed as 32-byte rows and expanded in registers), ragged M / N / K tiles included."""
+    """Nibble-packed weights (packed rows are DMA-ed as 64-byte rows and expanded in registers), ragged M / N / K
+    tiles included."""
     x = h16(1, M, K, scale=1.5, seed=M + K)
     W = h16(N, K, scale=0.04, seed=N)
     b = h16(N, scale=0.1, seed=5).float()
@@ -220,7 +192,7 @@ def test_gemm_epilogues(ops, dev):
     qa = ops.rowquant(x.to(dev))
     d, z = ops.weight_minmax(W.to(dev), 8)
     pw = ops.pack_weight(W.to(dev), d, z, 8)
-    for variant in (0, 4, 8, 9, 10):
+    for variant in GEMM_VARIANTS:
         out = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=ops.EPI_GELU, variant=variant).cpu().float()
         assert rel_l2(out, fq.gelu_tanh(y)) < 5e-4
         out = ops.gemm_i8(qa, pw, bias=b.to(dev), epilogue=ops.EPI_RESID, resid=resid.to(dev), variant=variant)

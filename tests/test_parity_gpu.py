@@ -434,3 +434,74 @@ def test_kv_linear_eps_fill_is_flagged_at_model_level(dev, ops):
     assert any("1e-6" in str(i.message) for i in w)
     with pytest.raises(RuntimeError):
         qnn.check_status(raise_on_eps=True)
+
+
+# ----------------------------------------------------------------------------- prompt sharding: 1 rank == N ranks
+def _tiny_sharded_job(dev, rank, world, n_prompts=3, steps=2):
+    import viditq_amd  # noqa
+    from viditq_amd import shard, synth
+    from viditq_amd.config import loads_yaml
+    from viditq_amd.t2v import IDDPM
+    m = synth.build_stdit(dev, depth=2, hidden_size=64, num_heads=4, input_size=(4, 8, 8), model_max_length=12,
+                          caption_channels=32, seed=0)
+    cfg = loads_yaml(synth.W8A8_DYNAMIC)
+    cfg.quant.activation.quantizer["n_spatial_token"], cfg.quant.activation.quantizer["n_temporal_token"] = 16, 4
+    qnn = shard.quantize_and_distribute(m, cfg, rank, world)
+    embeds, _ = synth.synthetic_prompts(n_prompts, dev, model_max_length=12, caption_channels=32)
+    sch = IDDPM(num_sampling_steps=steps, cfg_scale=4.0)
+    return shard.sample_sharded(qnn, sch, embeds, n_prompts, rank, world, z_size=(4, 4, 8, 8), seed=42)
+
+
+def test_sample_sharded_world1_equals_per_prompt_loops(dev, ops):
+    """shard.sample_sharded at world 1 = one DDIM loop per prompt with the per-prompt noise generator (seed + index):
+    the property that makes an N-rank run reproduce the 1-rank latents."""
+    import viditq_amd  # noqa
+    from viditq_amd import shard, synth
+    from viditq_amd.config import loads_yaml
+    from viditq_amd.t2v import IDDPM
+    full = _tiny_sharded_job(dev, 0, 1)
+    assert full.shape == (3, 4, 4, 8, 8) and torch.isfinite(full).all()
+    m = synth.build_stdit(dev, depth=2, hidden_size=64, num_heads=4, input_size=(4, 8, 8), model_max_length=12,
+                          caption_channels=32, seed=0)
+    cfg = loads_yaml(synth.W8A8_DYNAMIC)
+    cfg.quant.activation.quantizer["n_spatial_token"], cfg.quant.activation.quantizer["n_temporal_token"] = 16, 4
+    qnn = synth.quantize_model(m, cfg)
+    embeds, _ = synth.synthetic_prompts(3, dev, model_max_length=12, caption_channels=32)
+    sch = IDDPM(num_sampling_steps=2, cfg_scale=4.0)
+    for i in (2, 0):                                               # any order, any subset: same latents
+        z = synth.synthetic_latent(i, z_size=(4, 4, 8, 8), seed=42, device=dev)
+        y = embeds["y"][i:i + 1].permute(1, 0, 2, 3, 4).reshape(2, 1, 12, 32)
+        out = sch.ddim_sample_loop(qnn, z, dict(y=y, mask=embeds["mask"][i:i + 1]))
+        assert torch.equal(out[0], full[i])
+
+
+def _sharded_worker(rank, world, port, ret):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        with torch.no_grad():
+            full = _tiny_sharded_job(dev, rank, world)             # RCCL broadcast of the arena + all_gather of latents
+            if rank == 0:
+                ref = _tiny_sharded_job(dev, 0, 1)
+                ret["equal"] = bool(torch.equal(full, ref))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU tier)")
+def test_sample_sharded_world2_equals_world1_bit_for_bit():
+    """Two ranks over RCCL: rank 0 packs, ONE broadcast, prompts 0,2 on rank 0 and 1 on rank 1, all_gather - and the
+    gathered latents equal the single-rank run bit for bit (reference: single device only, quant_txt2video.py:71-72)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_sharded_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get("equal") is True

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import viditq_amd  # noqa
 from viditq_amd import ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 dev = torch.device("cuda:0")
 PEAK_I8 = 5.03e15
@@ -42,7 +44,7 @@ def main():
         out = torch.empty((M, N), dtype=torch.float16, device=dev)
         for variant in (0, 3, 4, 5, 6):
             try:
-                t = timeit(lambda: ops.gemm_i8(qa, pw, out=out, variant=variant))
+                t = timeit(lambda: lab.gemm_i8(qa, pw, out=out, variant=variant))
             except Exception as e:  # noqa
                 res["gemm_%dx%d_v%d" % (N, K, variant)] = str(e)
                 continue
@@ -50,7 +52,7 @@ def main():
             res["gemm_%dx%d_v%d" % (N, K, variant)] = {"us": t * 1e6, "TOPS": tops / 1e12, "frac": tops / PEAK_I8}
         d4, z4 = ops.weight_minmax(W, 4)
         pw4 = ops.pack_weight(W, d4, z4, 4)
-        t = timeit(lambda: ops.gemm_i8(qa, pw4, out=out, variant=0))
+        t = timeit(lambda: lab.gemm_i8(qa, pw4, out=out, variant=0))
         res["gemm_w4_%dx%d_v0" % (N, K)] = {"us": t * 1e6, "TOPS": 2.0 * M * N * K / t / 1e12}
         t = timeit(lambda: ops.rowquant(x))
         res["rowquant_K%d" % K] = {"us": t * 1e6, "GBps": (M * K * 3) / t / 1e9}

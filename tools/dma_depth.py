@@ -7,6 +7,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd  # noqa
 from viditq_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 lib = _lib.load()
 out = torch.zeros(512, dtype=torch.int32, device="cuda")
@@ -17,11 +19,11 @@ for stride in (1152, 4608):
                              (421, 128, 1), (422, 128, 2)]:
         it = (stride // bkb) * 40
         for _ in range(2):
-            lib.vq_probe_stage_rate(mode, src.data_ptr(), stride, it, 256, out.data_ptr(), st)
+            lab.lib().vq_probe_stage_rate(mode, src.data_ptr(), stride, it, 256, out.data_ptr(), st)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        lib.vq_probe_stage_rate(mode, src.data_ptr(), stride, it, 256, out.data_ptr(), st)
+        lab.lib().vq_probe_stage_rate(mode, src.data_ptr(), stride, it, 256, out.data_ptr(), st)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)

@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd  # noqa
 from viditq_amd import ops
 from tools.bench_kernels import timeit
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 dev = torch.device("cuda:0")
 M = 16384
@@ -24,5 +26,5 @@ for (N, K) in [(1152, 4608), (1152, 1152)]:
     d, z = ops.weight_minmax(W, 8)
     pw = ops.pack_weight(W, d, z, 8)
     for v in (11, 101, 102, 103, 104, 105, 108, 109, 110, 112, 113):
-        t = timeit(lambda: ops.gemm_i8(qa, pw, out=out, variant=v), iters=30)
+        t = timeit(lambda: lab.gemm_i8(qa, pw, out=out, variant=v), iters=30)
         print("N%d K%d %-36s %.1f us" % (N, K, names[v], t * 1e6), flush=True)

@@ -2,6 +2,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd
 from viditq_amd import ops
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 dev = torch.device("cuda:0")
 M, N, K = 16384, int(sys.argv[1]), int(sys.argv[2])
 v = int(sys.argv[3])
@@ -15,4 +18,4 @@ def t(fn, it=30):
     e0.record()
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it * 1e3
-print("N", N, "K", K, "variant", v, "nkt_env", os.environ.get("VQ_GEMM_NKT"), "us %.2f" % t(lambda: ops.gemm_i8(qa, pw, out=out, variant=v)))
+print("N", N, "K", K, "variant", v, "nkt_env", os.environ.get("VQ_GEMM_NKT"), "us %.2f" % t(lambda: lab.gemm_i8(qa, pw, out=out, variant=v)))

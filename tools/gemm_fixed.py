@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd  # noqa
 from viditq_amd import ops
 from tools.bench_kernels import timeit
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 dev = torch.device("cuda:0")
 M = 16384
@@ -22,7 +24,7 @@ for N in (1152, 3456, 4608):
         d, z = ops.weight_minmax(W, 8)
         pw = ops.pack_weight(W, d, z, 8)
         for v in (10, 11):
-            t = timeit(lambda: ops.gemm_i8(qa, pw, out=out, variant=v), iters=50)
+            t = timeit(lambda: lab.gemm_i8(qa, pw, out=out, variant=v), iters=50)
             print("N%d K%d v%d: %.1f us" % (N, K, v, t * 1e6), flush=True)
     t = timeit(lambda: out.fill_(1.0), iters=50)
     print("N%d fill fp16 [M,N]: %.1f us  (%.2f TB/s)" % (N, t * 1e6, M * N * 2 / t / 1e12))

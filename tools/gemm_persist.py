@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd  # noqa
 from viditq_amd import ops
 from tools.bench_kernels import timeit
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 dev = torch.device("cuda:0")
 M = 16384
@@ -23,8 +25,8 @@ for N, K, epi in ((3456, 1152, ops.EPI_NONE), (4608, 1152, ops.EPI_GELU), (4608,
     outs = {}
     for v in (11, 14):
         out = torch.empty((M, N), dtype=torch.float16, device=dev)
-        ops.gemm_i8(qa, pw, bias=b, out=out, epilogue=epi, variant=v)
-        t = timeit(lambda: ops.gemm_i8(qa, pw, bias=b, out=out, epilogue=epi, variant=v), iters=100)
+        lab.gemm_i8(qa, pw, bias=b, out=out, epilogue=epi, variant=v)
+        t = timeit(lambda: lab.gemm_i8(qa, pw, bias=b, out=out, epilogue=epi, variant=v), iters=100)
         outs[v] = out
         print("N%d K%d epi%d v%d: %.1f us" % (N, K, epi, v, t * 1e6), flush=True)
     print("   bit-identical:", bool(torch.equal(outs[11], outs[14])), flush=True)

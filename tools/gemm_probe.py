@@ -7,6 +7,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd  # noqa
 from viditq_amd import ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 dev = torch.device("cuda:0")
 M = 16384
@@ -22,6 +24,6 @@ pw = ops.pack_weight(W, d, z, 8)
 out = torch.empty((M, N), dtype=torch.float16, device=dev)
 for v in variants:
     for _ in range(iters):
-        ops.gemm_i8(qa, pw, out=out, variant=v)
+        lab.gemm_i8(qa, pw, out=out, variant=v)
 torch.cuda.synchronize()
 print("done")

@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd  # noqa
 from viditq_amd import ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 dev = torch.device("cuda:0")
 M = 16384
@@ -23,7 +25,7 @@ for (N, K) in [(1152, 1152), (4608, 1152), (1152, 4608)]:
     tiles = (M // 256) * (N // 288)
     stamps = torch.zeros(tiles * 8 * 10, dtype=torch.int64, device=dev)
     for _ in range(3):
-        ops.gemm_i8(qa, pw, out=out, variant=VARIANT, gate=stamps.view(torch.float32))
+        lab.gemm_i8(qa, pw, out=out, variant=VARIANT, gate=stamps.view(torch.float32))
     torch.cuda.synchronize()
     s = stamps.view(tiles, 8, 10).cpu().double()
     t0 = s[:, :, 0].min()                       # first wave start on the chip

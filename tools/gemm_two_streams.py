@@ -10,6 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd  # noqa
 from viditq_amd import ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 dev = torch.device("cuda:0")
 M = 16384
@@ -27,9 +29,9 @@ for (N, K) in [(1152, 1152), (3456, 1152), (4608, 1152), (1152, 4608)]:
         def run(n):
             for _ in range(n):
                 with torch.cuda.stream(s1):
-                    ops.gemm_i8(qa, pw, out=o1, variant=v)
+                    lab.gemm_i8(qa, pw, out=o1, variant=v)
                 with torch.cuda.stream(s2):
-                    ops.gemm_i8(qa, pw, out=o2, variant=v)
+                    lab.gemm_i8(qa, pw, out=o2, variant=v)
         try:
             run(3)
             torch.cuda.synchronize()

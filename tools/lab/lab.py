@@ -1,0 +1,57 @@
+"""ctypes binding of tools/lab/libviditq_lab.so (retired GEMM variants, ablations, probes) for the measurement
+scripts in tools/.  ``gemm_i8`` has the signature of viditq_amd.ops.gemm_i8 with a mandatory ``variant``."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import viditq_amd  # noqa: E402,F401
+from viditq_amd import ops  # noqa: E402
+
+_vp, _i = C.c_void_p, C.c_int
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "libviditq_lab.so")
+        if not os.path.exists(path):
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("lab_build", os.path.join(HERE, "build.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.build()
+        _lib = C.CDLL(path)
+        _lib.vq_lab_gemm_i8.restype = _i
+        _lib.vq_lab_gemm_i8.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
+        _lib.vq_probe_mfma_i8.argtypes = [_vp, _vp, _vp, _vp]
+        _lib.vq_probe_stage_rate.argtypes = [_i, _vp, _i, _i, _i, _vp, _vp]
+        _lib.vq_probe_mfma_rate.argtypes = [_i, _i, _i, _vp, _vp]
+    return _lib
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm_i8(a, w, bias=None, out=None, epilogue=0, resid=None, gate=None, rows_per_gate=0, variant=11):
+    M, N = a.rows, w.N
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=a.xq.device)
+    rc = lib().vq_lab_gemm_i8(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs), _p(bias),
+                              _p(out), out.stride(0), _p(resid), _p(gate), rows_per_gate, M, N, a.K, a.Kp, w.n_bits,
+                              epilogue, variant, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("vq_lab_gemm_i8 variant %d: error %d" % (variant, rc))
+    return out
+
+
+def probe_mfma_i8(a, b):
+    out = torch.empty((32, 32), dtype=torch.int32, device=a.device)
+    rc = lib().vq_probe_mfma_i8(_p(a), _p(b), _p(out), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    return out

@@ -1,6 +1,6 @@
 // probe.hip - micro-benchmarks of the MFMA / LDS / barrier mix used by the GEMM main loop.
 // Test infrastructure of the library itself (tools/mfma_rate.py); not on the product path.
-#include "vq_common.h"
+#include "../../vidit-q_amd/csrc/vq_common.h"
 
 // mode bit0: 13 ds_read_b128 per iteration; bit1: workgroup barrier per iteration;
 // bit2: use 32x32x32 MFMAs (9 per iteration) instead of 36 16x16x64

@@ -9,6 +9,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import viditq_amd  # noqa
 from viditq_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab  # noqa: E402  (tools/lab: retired variants / probes live outside the product library)
 
 lib = _lib.load()
 out = torch.zeros(512, dtype=torch.int32, device="cuda")
@@ -19,7 +21,7 @@ for mode, name in ((0, "36 x mfma_i32_16x16x64_i8 per iteration, 8 waves/CU"), (
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
     ev[0].record()
     for i in range(n):
-        lib.vq_probe_mfma_rate(mode, iters, blocks, out.data_ptr(), st)
+        lab.lib().vq_probe_mfma_rate(mode, iters, blocks, out.data_ptr(), st)
         ev[i + 1].record()
     smi = subprocess.run("sleep 1.5; rocm-smi --showpower --showclocks 2>/dev/null | grep -iE 'power|sclk|mclk|fclk' | head -8",
                          shell=True, capture_output=True, text=True).stdout

@@ -36,9 +36,6 @@ SIGNATURES = {
     "vq_attn_temporal": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _f, _vp]),
     "vq_attn_temporal_rowquant": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _i, _f, _vp]),
     "vq_adaln_table": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    "vq_probe_mfma_i8": (_i, [_vp, _vp, _vp, _vp]),
-    "vq_probe_stage_rate": (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
-    "vq_probe_mfma_rate": (_i, [_i, _i, _i, _vp, _vp]),
     "vq_cfg_ddim_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
 }
 

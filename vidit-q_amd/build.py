@@ -7,11 +7,11 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libviditq_hip.so")
-SOURCES = ["api.hip", "rowquant.hip", "rowquant_fast.hip", "pack.hip", "gemm_i8.hip", "attention.hip", "sampler.hip", "probe.hip"]
+SOURCES = ["api.hip", "rowquant.hip", "rowquant_fast.hip", "pack.hip", "gemm_i8.hip", "attention.hip", "sampler.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # sources whose MFMA accumulators stay in VGPRs: the AGPR form costs a v_accvgpr_read/write per softmax /
 # epilogue operand (attention).  VQ_VGPR_FORM="a.hip,b.hip" overrides the set for experiments.
-VGPR_FORM = {"attention.hip", "gemm_i8.hip", "probe.hip"}
+VGPR_FORM = {"attention.hip", "gemm_i8.hip"}
 
 
 def _flags(src: str):
@@ -49,8 +49,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if not os.path.exists(sp):
             continue
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(sp)
-                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, "vq_common.h"))):
+        hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_t):
             procs.append((src, obj, None))
             continue
         cmd = [hipcc, *_flags(src), "-c", sp, "-o", obj]

@@ -1,0 +1,235 @@
+// gemm_wide.h - the full-line ring kernel (256 x 288 tile, 8 waves); see csrc/gemm_i8.hip for the design notes.
+#pragma once
+#include "gemm_common.h"
+
+// ---------------------------------------------------------------------------
+// Full-line ring kernel (variant 11).  tools/dma_depth.py: the L2 -> LDS fill rate of a CU is bound by
+// cache-line REQUESTS, not bytes: 64-byte row chunks (BK 64) stream at 65 GB/s per CU, 128-byte
+// chunks (one whole line per row) at 127 GB/s.  A 256 x 288 tile at full MFMA rate consumes 63 GB/s,
+// so the BK-64 ring ran AT its fill limit.  Here a stage holds 128 bytes of k per row (two MFMA
+// k-steps), every DMA lane group fetches whole lines, and the ring is a plain double buffer (2 x 68 KiB):
+//   tile kt:  step h=0 | step h=1 ... [j = TN-2: vmcnt(0) + barrier -> DMA(kt+1) landed, stage kt free]
+//   DMA(kt+2) into the freed stage is issued by waves 0..NW/2-1 right after that barrier and by their
+//   SIMD partners NW/2.. a few MFMA groups into the next tile (an LDS-DMA issue blocks the issuing wave
+//   for ~100 cycles; staggering keeps one partner on the MFMA pipe).
+// LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row >> 1) & 7 (W4: 64 B rows, (row >> 2) & 3).
+// ---------------------------------------------------------------------------
+// ABL (profiling only, results wrong): 1 no DMA after the prologue, 2 no MFMA, 4 no barrier, 8 no fragment reads
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(GemmArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int WROW = W4 ? 64 : 128;               // bytes per weight row and stage
+    constexpr int XP = BM / 8, WP = BN * WROW / 1024; // 1 KiB DMA pieces
+    constexpr int STAGE = BM * 128 + BN * WROW;
+    constexpr int PIECES = XP + WP;
+    constexpr int PPW = (PIECES + NW - 1) / NW;
+    constexpr int PLAST = PIECES - (PPW - 1) * NW;
+    constexpr int BARJ = TN - 2;                      // after the last fragment read of the current stage
+    constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (next tile)
+    static_assert(TM == 4 && TN >= 3 && TN % 3 == 0, "fragment rings below");
+    static_assert(BN * WROW % 1024 == 0 && STAGE % 128 == 0, "whole pieces, 128-byte aligned stages");
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // ABL & 16: cycle-counter stamps of every wave -> a.gate reinterpreted as long long[tiles][waves][10] (0-6 shader cycles, 7/8 100 MHz wall clock at start/end)
+    long long* ts = nullptr;
+    if constexpr ((ABL & 16) != 0)
+        ts = reinterpret_cast<long long*>(const_cast<float*>(a.gate)) + ((size_t)blockIdx.x * (WAVES_M * WAVES_N) + (threadIdx.x >> 6)) * 10;
+    if (ts) {
+        ts[7] = wall_clock64();
+        ts[0] = __builtin_readcyclecounter();
+    }
+
+    int mt_, nt_;
+    {
+        const int MT_ = (a.M + BM - 1) / BM, NT_ = (a.N + BN - 1) / BN;
+        int vb = blockIdx.x;
+        if (a.nbatch > 1) {                            // batch-major grid: weight set = blockIdx / tiles
+            const int bt = vb / (MT_ * NT_);
+            vb -= bt * (MT_ * NT_);
+            a.wq += (size_t)bt * a.bs_w;
+            a.sw += (size_t)bt * a.bs_ch;
+            a.zw += (size_t)bt * a.bs_ch;
+            a.cs += (size_t)bt * a.bs_ch;
+            if (a.bias) a.bias += (size_t)bt * a.bs_ch;
+            a.out += (size_t)bt * a.bs_out;
+        }
+        xcd_tile(vb, MT_, NT_, mt_, nt_);
+    }
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const bool full_wave = (PIECES % NW == 0) || wave < PLAST;
+    const bool late = STAGGER && wave >= NW / 2;      // wave-uniform
+
+    uint32_t soff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + i * NW;
+        if (p < XP) {
+            const int r = p * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gm = m0 + r;
+            gm = gm < a.M ? gm : a.M - 1;
+            soff[i] = (uint32_t)gm * (uint32_t)a.Kp + c * 16;
+        } else if (!W4) {
+            const int r = (p - XP) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gn = n0 + r;
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)a.Kp + c * 16;
+        } else {
+            const int r = (p - XP) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((r >> 2) & 3);
+            int gn = n0 + r;
+            gn = gn < a.N ? gn : a.N - 1;
+            soff[i] = (uint32_t)gn * (uint32_t)(a.Kp >> 1) + c * 16;
+        }
+    }
+    const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
+    auto issue = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + i * NW;
+            if (PIECES % NW == 0 || p < PIECES) {
+                const uint8_t* g = p < XP ? xbase + soff[i] + kt * 128 : a.wq + soff[i] + kt * WROW;
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                                 (void __attribute__((address_space(3)))*)(smem + stage * STAGE + p * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    int4v acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
+
+    const int frow = lane & 15, fc = lane >> 4;
+    // k-step h (0/1) of a stage = chunks 4h..4h+3 of the 128-byte row: the swizzled address of step 1 is
+    // the address of step 0 with bit 6 flipped (W4: 8-byte reads of a 64-byte row, bit 5)
+    const int xf0 = (wm * WTM + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int wf0 = W4 ? BM * 128 + (wn * WTN + frow) * 64 + (((fc >> 1) ^ ((frow >> 2) & 3)) * 16) + (fc & 1) * 8
+                       : BM * 128 + (wn * WTN + frow) * 128 + ((fc ^ ((frow >> 1) & 7)) * 16);
+    const int xf1 = xf0 ^ 64, wf1 = wf0 ^ (W4 ? 32 : 64);
+    using WRaw = typename std::conditional<W4, int2v, int4v>::type;
+    auto ldx = [&](int stage, int h, int i) {
+        return *reinterpret_cast<const int4v*>(smem + stage * STAGE + (h ? xf1 : xf0) + i * 16 * 128);
+    };
+    auto ldw = [&](int stage, int h, int j) {
+        return *reinterpret_cast<const WRaw*>(smem + stage * STAGE + (h ? wf1 : wf0) + j * 16 * WROW);
+    };
+    auto wop = [&](const WRaw& r) -> int4v {
+        if constexpr (W4) {
+            return int4v{r[0] & 0x0F0F0F0F, (int)(((uint32_t)r[0] >> 4) & 0x0F0F0F0Fu), r[1] & 0x0F0F0F0F,
+                         (int)(((uint32_t)r[1] >> 4) & 0x0F0F0F0Fu)};
+        } else {
+            return r;
+        }
+    };
+
+    const int nkt = a.Kp / 128;
+    issue(0, 0);
+    if (nkt > 1) {
+        issue(1, 1);
+        if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (ts) ts[1] = __builtin_readcyclecounter();
+    int4v xa[TM], xb[TM];
+    WRaw w[3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xa[i] = ldx(0, 0, i);
+    w[0] = ldw(0, 0, 0);
+    w[1] = ldw(0, 0, 1);
+
+#define VQ_WIDE_STEP(X, XN, H)                                                                             \
+    {                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+            if (H == 1 && j == BARJ && more) {                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+                if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                              \
+                if (!(ABL & 1) && !late && kt + 2 < nkt) issue(cur, kt + 2);                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (!(ABL & 1) && H == 0 && j == DMA_B && late && kt >= 1 && more) {                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                issue(nxt, kt + 1);                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (ABL & 8) {                                                                                 \
+            } else if (j + 2 < TN) w[(j + 2) % 3] = ldw(cur, H, j + 2);                                    \
+            else if (H == 0) w[(j + 2) % 3] = ldw(cur, 1, j + 2 - TN);                                     \
+            else if (more) w[(j + 2) % 3] = ldw(nxt, 0, j + 2 - TN);                                       \
+            if (!(ABL & 8) && (H == 0 || more)) {                                                                          \
+                if (j == TN - 2) { XN[0] = ldx(H == 0 ? cur : nxt, 1 - H, 0); XN[1] = ldx(H == 0 ? cur : nxt, 1 - H, 1); } \
+                if (j == TN - 1) { XN[2] = ldx(H == 0 ? cur : nxt, 1 - H, 2); XN[3] = ldx(H == 0 ? cur : nxt, 1 - H, 3); } \
+            }                                                                                              \
+            const int4v wv_ = wop(w[j % 3]);                                                               \
+            if (ABL & 2) {                                                                                 \
+                asm volatile("" ::"v"(wv_), "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]));                   \
+            } else {                                                                                       \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+                    acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv_, X[i], acc[j][i], 0, 0, 0);      \
+            }                                                                                              \
+            if (j >= TN - 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                            \
+            else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
+        }                                                                                                  \
+    }
+    // ABL & 32 (experiment): static priority for the later-dispatched half of the waves - measured 12 % SLOWER
+    // main loop (29.7 k vs 26.6 k cycles), so off
+    if ((ABL & 32) != 0 && late) __builtin_amdgcn_s_setprio(1);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1, nxt = cur ^ 1;
+        const bool more = kt + 1 < nkt;
+        VQ_WIDE_STEP(xa, xb, 0)
+        VQ_WIDE_STEP(xb, xa, 1)
+    }
+    if ((ABL & 32) != 0) __builtin_amdgcn_s_setprio(0);
+#undef VQ_WIDE_STEP
+    if (ts) ts[2] = __builtin_readcyclecounter();
+    const float* gate_row = EPI == VQ_EPI_GATE_RESID ? ring_tile_gate_row<BM>(a, m0) : nullptr;
+    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0, -1, gate_row);
+    __syncthreads();
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts, -1, gate_row != nullptr);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
+static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4 + 12 * BM;
+    constexpr size_t LDS = RING > EPIL ? RING : EPIL;
+    static_assert(LDS <= 163840, "LDS budget of one CU");
+    const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    auto k = gemm_i8_wide_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4>;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3(MT * NTl * (a.nbatch > 1 ? a.nbatch : 1)), dim3(NT), LDS, st, a);
+    return vq_check_launch();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STAGGER, bool W4 = false>
+static int launch_gemm_wide(const GemmArgs& a, hipStream_t st) {
+    switch (a.epilogue) {
+        case VQ_EPI_NONE: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, STAGGER, W4>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, STAGGER, W4>(a, st);
+        case VQ_EPI_GATE_RESID:
+            return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, STAGGER, W4>(a, st);
+        default: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, STAGGER, W4>(a, st);
+    }
+}

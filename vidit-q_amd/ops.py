@@ -257,10 +257,10 @@ def pack_weight(W: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, n_bits: 
 # When set to a list, every GEMM launch is bracketed by two events recorded on the launch stream and
 # (start, end, int8_ops, algorithmic_bytes) is appended - bench.py's live roofline measurement.
 GEMM_TIMING = None
-# kernel variant used when the caller does not choose: 11 = full-line (128 B of k per row) double-buffered
-# LDS-DMA ring, staggered DMA issue, LDS-transposed coalesced epilogue, 256x288 tile (csrc/gemm_i8.hip);
-# nibble-packed (<= 4 bit) weights take the same kernel with 64-byte packed rows
-DEFAULT_GEMM_VARIANT = 11
+# kernel used when the caller does not choose: -1 = the library's own choice per shape (VQ_GEMM_DEFAULT);
+# 11 pins the full-line (128 B of k per row) double-buffered LDS-DMA ring, 256x288 tile (csrc/gemm_wide.h);
+# nibble-packed (<= 4 bit) weights take the same kernels with 64-byte packed rows
+DEFAULT_GEMM_VARIANT = -1
 
 
 def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
@@ -420,12 +420,4 @@ def cfg_ddim_step(cond: torch.Tensor, uncond: torch.Tensor, x: torch.Tensor, cfg
         out = torch.empty_like(x)
     check(_L().vq_cfg_ddim_step(_p(cond), _p(uncond), _p(x), _p(out), n, Cc, inner, float(cfg), float(one_plus_k),
                                 float(A), float(Bc), float(abar_prev), _stream()), "vq_cfg_ddim_step")
-    return out
-
-
-def probe_mfma_i8(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    _req(a, torch.int8, "a")
-    _req(b, torch.int8, "b")
-    out = torch.empty((32, 32), dtype=torch.int32, device=a.device)
-    check(_L().vq_probe_mfma_i8(_p(a), _p(b), _p(out), _stream()), "vq_probe_mfma_i8")
     return out
