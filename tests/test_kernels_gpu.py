@@ -464,3 +464,33 @@ def test_gemm_i8_batched_equals_separate_launches(ops, dev):
     assert got.shape == (nb, M, N)
     for b in range(nb):
         assert torch.equal(got[b], outs[b])
+
+
+@pytest.mark.parametrize("w_bits", [8, 4])
+@pytest.mark.parametrize("epi", ["none", "gelu", "resid", "gate"])
+def test_gemm_interior_epilogue_is_bit_identical_to_general_path(ops, dev, epi, w_bits):
+    """Full tiles take a lean epilogue (incremental chunk walk, SGPR base + 32-bit offsets, v_pk_add_f16 residual
+    add); ragged tiles and row pitches that are not a multiple of 8 take the general one.  Same arithmetic: the two
+    must agree bit for bit (a pitch of N + 4 forces the general path on the same problem)."""
+    M, N, K = 1024, 1152, 384
+    x = h16(2, M // 2, K, scale=1.5, seed=3)
+    W = h16(N, K, scale=0.04, seed=4)
+    b = h16(N, scale=0.1, seed=5).float().to(dev)
+    qa = ops.rowquant(x.to(dev))
+    d, z = ops.weight_minmax(W.to(dev), w_bits)
+    pw = ops.pack_weight(W.to(dev), d, z, w_bits)
+    resid = h16(M, N, scale=1.0, seed=6).to(dev)
+    gate = h16(2, N, scale=0.5, seed=7).float().to(dev)
+    kw = {"none": dict(), "gelu": dict(epilogue=ops.EPI_GELU), "resid": dict(epilogue=ops.EPI_RESID),
+          "gate": dict(epilogue=ops.EPI_GATE_RESID, gate=gate, rows_per_gate=M // 2)}[epi]
+    wide = torch.zeros(M, N + 4, dtype=torch.float16, device=dev)
+    rwide = torch.zeros(M, N + 4, dtype=torch.float16, device=dev)
+    rwide[:, :N] = resid
+    if epi in ("resid", "gate"):
+        fast = ops.gemm_i8(qa, pw, bias=b, resid=resid, **kw)
+        slow = ops.gemm_i8(qa, pw, bias=b, out=wide, resid=rwide, **kw)[:, :N]
+    else:
+        fast = ops.gemm_i8(qa, pw, bias=b, **kw)
+        slow = ops.gemm_i8(qa, pw, bias=b, out=wide, **kw)[:, :N]
+    assert torch.equal(fast, slow)
+    assert torch.all(wide[:, N:] == 0)
