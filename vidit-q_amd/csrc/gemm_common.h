@@ -40,6 +40,8 @@ struct GemmArgs {
     // of the respective arrays (wq bytes, per-channel arrays, out halves)
     int nbatch;
     long bs_w, bs_ch, bs_out;
+    int grid_limit;   // > 0: at most this many workgroups (a multiple of 8); they walk the tiles persistently
+    int total_tiles;  // set by the launcher for the persistent walk
 };
 
 // Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (bid % 8), each with its own 4 MiB

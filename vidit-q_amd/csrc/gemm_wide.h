@@ -15,8 +15,12 @@
 // LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row >> 1) & 7 (W4: 64 B rows, (row >> 2) & 3).
 // ---------------------------------------------------------------------------
 // ABL (profiling only, results wrong): 1 no DMA after the prologue, 2 no MFMA, 4 no barrier, 8 no fragment reads
+// PERSIST: the grid is smaller than the tile count and workgroup b walks tiles b, b + G, b + 2G, ... (G a multiple of 8,
+// so a workgroup stays on the XCD whose L2 holds its operand panels).  A grid of fewer workgroups than CUs leaves
+// whole CUs to the other stream's kernels (cond / uncond run as two streams): the HBM-bound quantizer / attention
+// kernels of one sample then run BESIDE the other sample's GEMM instead of queueing behind its full-chip launch.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>
-__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, const int tid_) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
     // ABL & 16: cycle-counter stamps of every wave -> a.gate reinterpreted as long long[tiles][waves][10] (0-6 shader cycles, 7/8 100 MHz wall clock at start/end)
     long long* ts = nullptr;
     if constexpr ((ABL & 16) != 0)
-        ts = reinterpret_cast<long long*>(const_cast<float*>(a.gate)) + ((size_t)blockIdx.x * (WAVES_M * WAVES_N) + (threadIdx.x >> 6)) * 10;
+        ts = reinterpret_cast<long long*>(const_cast<float*>(a.gate)) + ((size_t)vb0 * (WAVES_M * WAVES_N) + (tid_ >> 6)) * 10;
     if (ts) {
         ts[7] = wall_clock64();
         ts[0] = __builtin_readcyclecounter();
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
     int mt_, nt_;
     {
         const int MT_ = (a.M + BM - 1) / BM, NT_ = (a.N + BN - 1) / BN;
-        int vb = blockIdx.x;
+        int vb = vb0;
         if (a.nbatch > 1) {                            // batch-major grid: weight set = blockIdx / tiles
             const int bt = vb / (MT_ * NT_);
             vb -= bt * (MT_ * NT_);
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
     }
     const int m0 = mt_ * BM, n0 = nt_ * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const bool full_wave = (PIECES % NW == 0) || wave < PLAST;
@@ -199,9 +203,29 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
 #undef VQ_WIDE_STEP
     if (ts) ts[2] = __builtin_readcyclecounter();
     const float* gate_row = EPI == VQ_EPI_GATE_RESID ? ring_tile_gate_row<BM>(a, m0) : nullptr;
-    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0, -1, gate_row);
+    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0, tid, gate_row);
     __syncthreads();
-    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts, -1, gate_row != nullptr);
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts, tid, gate_row != nullptr);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(GemmArgs a) {
+    gemm_i8_wide_tile<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4, ABL>(a, blockIdx.x, threadIdx.x);
+}
+
+// PERSISTENT launch: the grid is smaller than the tile count and workgroup b walks tiles b, b + G, b + 2G, ... (G a
+// multiple of 8, so a workgroup stays on the XCD whose L2 holds its operand panels).  A grid of fewer workgroups than
+// CUs leaves whole CUs to the other stream's kernels (cond / uncond run as two streams): the HBM-bound quantizer /
+// attention kernels of one sample then run BESIDE the other sample's GEMM instead of queueing behind its full-chip
+// launch.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
+__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_persist_kernel(GemmArgs a) {
+    for (int vb0 = blockIdx.x; vb0 < a.total_tiles; vb0 += gridDim.x) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));      // opaque per tile: lane-dependent addresses are recomputed, not carried in VGPRs
+        gemm_i8_wide_tile<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4, 0>(a, vb0, tx);
+        __syncthreads();                  // every wave is done with its slab before the ring refills
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
@@ -212,6 +236,20 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
+    const int tiles = MT * NTl * (a.nbatch > 1 ? a.nbatch : 1);
+    if (a.grid_limit > 0 && tiles > a.grid_limit) {       // persistent walk on a.grid_limit workgroups
+        auto kp = gemm_i8_wide_persist_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4>;
+        static hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
+        if (ep != hipSuccess) {
+            g_vq_last_hip_error = (int)ep;
+            return VQ_ELAUNCH;
+        }
+        GemmArgs b = a;
+        b.total_tiles = tiles;
+        hipLaunchKernelGGL(kp, dim3(a.grid_limit), dim3(NT), LDS, st, b);
+        return vq_check_launch();
+    }
     auto k = gemm_i8_wide_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
@@ -219,7 +257,7 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
     }
-    hipLaunchKernelGGL(k, dim3(MT * NTl * (a.nbatch > 1 ? a.nbatch : 1)), dim3(NT), LDS, st, a);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), LDS, st, a);
     return vq_check_launch();
 }
 
