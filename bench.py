@@ -207,10 +207,11 @@ def main():
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)
         tot_ops = sum(o for _, _, o, _ in timing)
         ach = tot_ops / (tot_ms * 1e-3)
-        # HBM / fabric bytes per GEMM launch: PMC passes cannot run inside this process; the committed measurement
-        # of the same command (tools/pmc_traffic.sh -> profiles/r01_gemm_traffic.json) is reported for this plan
+        # HBM / fabric bytes per GEMM launch: PMC passes cannot run inside this process (rocprofv3 wraps the process);
+        # the committed measurement of THIS command on the shipping kernels at depth 28 (tools/measure_r02.sh ->
+        # profiles/r02_gemm_traffic.json, regenerated whenever a GEMM kernel changes) is reported for this plan
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
         if a.plan == "w8a8" and os.path.exists(tj):
             with open(tj) as f:
                 t_ = json.load(f)

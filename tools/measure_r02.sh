@@ -1,0 +1,31 @@
+# Round-2 evidence for profiles/: everything on the SHIPPING kernels, inside bench.py at depth 28.
+#   1. rocprofv3 --kernel-trace --stats of the default bench command (HIP graph, two streams)
+#   2. PMC passes of the same bench launched eagerly (every dispatch carries its counters), ONE counter set per pass,
+#      --kernel-trace only (no other trace domains): FETCH_SIZE, WRITE_SIZE, two SQ sets, GRBM
+#   3. FETCH/WRITE calibration on known byte counts
+# then: python tools/summarize_r02.py  ->  profiles/r02_*.  GPU box only.
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"
+R=$PWD
+O=$R/gpurun_out/r02
+mkdir -p $O
+EXTRA="$@"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline $EXTRA > $O/stats.log 2>&1)
+pass() {  # name, counters...
+  n=$1; shift
+  (cd /tmp && timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$n -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph --no-roofline-events $EXTRA > $O/$n.log 2>&1)
+}
+pass FETCH_SIZE FETCH_SIZE
+pass WRITE_SIZE WRITE_SIZE
+pass SQ1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS
+pass SQ2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU
+pass GRBM GRBM_GUI_ACTIVE GRBM_COUNT
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 100 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/cal_$c -o p -- python $R/tools/traffic_cal.py > $O/cal_$c.log 2>&1)
+done
+python bench.py $EXTRA > $O/bench_line.json 2> $O/bench.err
+python tools/summarize_r02.py r02 > $O/summary.log 2>&1
+# the raw per-dispatch counter tables are tens of MB: only the summaries (and the kernel stats) travel back
+for d in FETCH_SIZE WRITE_SIZE SQ1 SQ2 GRBM cal_FETCH_SIZE cal_WRITE_SIZE; do rm -rf $O/$d; done
+find $O/stats -type f ! -name "*kernel_stats.csv" -delete
+tail -c 300 $O/bench_line.json; cat $O/summary.log | tail -30
