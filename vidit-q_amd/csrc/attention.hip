@@ -973,291 +973,25 @@ __global__ __launch_bounds__(64 * NW, NQ == 2 ? 1 : 8 / NW) void attn_fwd8_kerne
 }
 
 // ---------------------------------------------------------------------------
-// attn_fwd_pp_kernel: the long-sequence flash kernel with the two waves of every SIMD in OPPOSITE phases.
-// Phase stamps of attn_fwd8_kernel (tools/attn_stamps.py) showed a 4100-cycle tile period for 704 cycles of MFMA issue
-// per wave: all 8 waves leave the per-tile barrier together, so on every SIMD both waves first contend for the matrix
-// pipe (QK^T), then both run the softmax on the VALU with the matrix pipe idle, then both contend again (P.V).
-// Here waves 0-3 (group A) and their SIMD partners 4-7 (group B) run half a tile apart, a barrier per half-step:
-//     half-step 2t     A: S = K[t] Q^T (+ stages K[t+1], requests K[t+2])     B: softmax + P.V of tile t-1
-//     half-step 2t+1   A: softmax + P.V of tile t                              B: S = K[t] Q^T (+ stages V[t+1], requests V[t+2])
-// so a QK^T segment (matrix pipe, LDS reads, staging) always sits beside a softmax / P.V segment (VALU, then matrix
-// pipe).  Group A stages every K tile and group B every V tile (256 threads each): one staging register set per
-// thread instead of four, loaded a whole tile before it is written.  Barriers are raw s_barrier behind
-// s_waitcnt lgkmcnt(0) - __syncthreads() would also wait (vmcnt(0)) for the tile requested a moment earlier.
-// K[t] is read at half-steps 2t (A) and 2t+1 (B), V[t] at 2t+1 (A) and 2t+2 (B): K[t+1] may be written into the other
-// K buffer from half-step 2t on (A does, at 2t), V[t+1] into the other V buffer from 2t+1 on (B does, at 2t+1).
-// Same arithmetic, LDS images, deferred rescale and output path as attn_fwd8_kernel.
+// attn_fwd32d_kernel: attn_fwd32h with the K / V tiles delivered by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
+// registers, no ds_write pass, no vmcnt coupling between the staged tile and the fragment reads.  A wave-instruction
+// fills 64 consecutive 16-byte slots of the tile image; slot -> (row, piece) is the ordinary padded row-major layout
+// (K rows KROW bytes, V rows 192 bytes with the ones column behind the data), lanes whose slot is padding are masked
+// off, rows past the last key are out of the buffer's range and land as zeros.  The ~15 VGPRs this frees pay for
+// fragment reads that run two ahead of the MFMAs (pinned with sched_barrier).
 // ---------------------------------------------------------------------------
-typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));   // operand type of the LDS transpose read
 
-template <int D, bool STAMP = false>
-__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgs a) {
-    constexpr int NW = 8;
+template <int D, int ABLD = 0, int NW = 8, int KT = 64>
+__global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs a) {
+    static_assert(KT % 64 == 0, "key tile in 64-row DMA units");
+    constexpr int KTB = (KT / 64) * Att8Cfg<D, 8>::KTILE;      // K tile bytes
     using C = Att8Cfg<D, NW>;
-    constexpr int GT = 256;                                 // threads per group
-    // V is staged ROW-major like K (one ds_write_b128 per 16-byte chunk, no transposing write pass): the P.V operand
-    // V^T[dim][8 keys] comes out of the gfx950 LDS transpose read (ds_read_b64_tr_b16: a 16-lane group reads a
-    // [4 keys][16 dims] block and every lane receives one dim's 4 keys).  Row stride 192 B = 48 dwords: the 4 rows of
-    // a block and the two dim halves of a 32-lane access fall on 8 disjoint 8-bank runs (conflict-free); the 24 pad
-    // columns hold {1.0, 0, ...}: column D is the ones column whose P.V product is the softmax row sum.
-    constexpr int VRB = 192, VT = 64 * VRB;
-    static_assert(D * 2 + 2 <= VRB && C::DT * 64 <= VRB, "dims + ones column inside a row; every 32-dim tile readable");
-    constexpr int SPT = (C::KCH + GT - 1) / GT;             // staging passes per thread and tile
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                              // 0: group A, 1: group B (wave-uniform)
-    const int tg = tid & (GT - 1);
-    const int g = lane >> 5, l31 = lane & 31;
-    int qt, h, seq;
-    {   // same XCD-aware (sequence, head, query tile) placement as attn_fwd8_kernel
-        const int nqt = (a.Lq + 32 * NW - 1) / (32 * NW);
-        const int G = a.n_seq * a.H;
-        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-        const int q8 = G / 8, r8 = G % 8;
-        const int gbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-        const int gcount = xcd < r8 ? q8 + 1 : q8;
-        const int pl = idx / nqt;
-        if (pl >= gcount) return;
-        const int pair = gbase + pl;
-        qt = idx - pl * nqt;
-        seq = pair / a.H;
-        h = pair - seq * a.H;
-    }
-    const int kv_len = a.Lk;
-    const half_t* kbase = a.k + (long)seq * a.kv_seq_stride + h * D;
-    const half_t* vbase = a.v + (long)seq * a.kv_seq_stride + h * D;
-    const int qi = qt * (32 * NW) + wave * 32 + l31;
-    const bool q_ok = qi < a.Lq;
-    half8 qf[C::KS];
-    float16v oacc[C::DT];
-    float m_run = -INFINITY;
-    {
-        const int qc = q_ok ? qi : a.Lq - 1;
-        const half_t* qrow = a.q + (long)seq * a.q_seq_stride + (long)qc * a.q_tok_stride + h * D;
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-            const int d0 = ks * 16 + 8 * g;
-            if (d0 < D) qf[ks] = *reinterpret_cast<const half8*>(qrow + d0);
-            else
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)0.f;
-        }
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    }
-    // transpose-read base of this lane: row 4g + (i >> 2), dims 16 * (lane bit 4) + 4 * (i & 3) of a [.][VRB] image
-    const int vtr0 = (4 * g + ((lane & 15) >> 2)) * VRB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    const int nkt = (kv_len + 63) / 64;
-
-    // ---- staging geometry of THIS thread: group A owns the K tiles, group B the V tiles (layouts: attn_fwd8_kernel)
-    bool act[SPT];
-    int srow[SPT], sdst[SPT];
-    long sgo[SPT];
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) {
-        const int c = tg + i * GT;
-        act[i] = c < C::KCH;
-        const int cc = act[i] ? c : 0;
-        srow[i] = cc / C::CHD;
-        sgo[i] = (long)srow[i] * a.kv_tok_stride + (cc % C::CHD) * 8;
-        sdst[i] = srow[i] * (grp == 0 ? C::KROW : VRB) + (cc % C::CHD) * 16;
-    }
-    const half_t* sbase = grp == 0 ? kbase : vbase;
-    int4v sr[SPT];
-    auto load_stage = [&](int kt) __attribute__((always_inline)) {
-        const long t0 = (long)kt * 64 * a.kv_tok_stride;
-        const bool full = kt * 64 + 64 <= kv_len;
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            if (act[i]) {
-                if (full) sr[i] = *reinterpret_cast<const int4v*>(sbase + t0 + sgo[i]);
-                else {
-                    const int r_ = kt * 64 + srow[i] < kv_len ? srow[i] : kv_len - 1 - kt * 64;
-                    sr[i] = *reinterpret_cast<const int4v*>(sbase + t0 + sgo[i] + (long)(r_ - srow[i]) * a.kv_tok_stride);
-                }
-            }
-        }
-    };
-    auto store_stage = [&](int buf) __attribute__((always_inline)) {
-        uint8_t* dst = grp == 0 ? smem + buf * C::KTILE : smem + 2 * C::KTILE + buf * VT;
-#pragma unroll
-        for (int i = 0; i < SPT; ++i)
-            if (act[i]) *reinterpret_cast<int4v*>(dst + sdst[i]) = sr[i];
-    };
-    auto wg_barrier = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes / reads are done; global loads stay in flight
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-
-    // pad columns of both V images (never touched by the staging stores): column D = 1.0, the rest 0
-    if (tid < 2 * 64 * 3) {
-        const int buf = tid / 192, r = (tid % 192) / 3, ch = tid % 3;
-        *reinterpret_cast<int4v*>(smem + 2 * C::KTILE + buf * VT + r * VRB + D * 2 + ch * 16) = int4v{ch == 0 ? 0x00003c00 : 0, 0, 0, 0};
-    }
-    if (nkt > 0) {
-        load_stage(0);
-        store_stage(0);
-        if (nkt > 1) load_stage(1);
-    }
-    wg_barrier();
-
-    float16v s[2];
-    long long* ts = nullptr;                                // STAMP: slots 5.. filled inside smpv
-    // S^T = K Q^T for the 64 keys of tile kt: k-step outer, sub-tile inner (two independent accumulator chains)
-    auto qk = [&](const int kt) __attribute__((always_inline)) {
-        const uint8_t* kt_ = smem + (kt & 1) * C::KTILE;
-        const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-            const int d0 = ks * 16 + 8 * g;
-            // lanes whose 8 dims lie past D read dims 0..7 of their own key row (finite data): their q fragment is zero
-#pragma unroll
-            for (int sc = 0; sc < 2; ++sc) {
-                const half8 kf = *reinterpret_cast<const half8*>(kt_ + (sc * 32 + l31) * C::KROW + (d0 < D ? d0 : 0) * 2);
-                s[sc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[sc], 0, 0, 0);
-            }
-        }
-        // stage the next tile of this group's operand under the MFMAs above, then request the one after it
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nkt) store_stage((kt + 1) & 1);
-        if (kt + 2 < nkt) load_stage(kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // online softmax of tile kt's scores and O^T += V^T P^T
-    auto smpv = [&](auto rag_tag, const int kt) __attribute__((always_inline)) {
-        constexpr bool RAG = decltype(rag_tag)::value;
-        const uint8_t* vt_ = smem + 2 * C::KTILE + (kt & 1) * VT + vtr0;
-        if constexpr (RAG) {
-#pragma unroll
-            for (int sc = 0; sc < 2; ++sc)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 64 + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    if (key >= kv_len) s[sc][r] = -INFINITY;
-                }
-        }
-        float mt[32];                                       // tree, not a 31-deep dependent chain
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            mt[r] = s[0][r];
-            mt[16 + r] = s[1][r];
-        }
-#pragma unroll
-        for (int n = 16; n >= 1; n >>= 1)
-#pragma unroll
-            for (int r = 0; r < n; ++r) mt[r] = fmaxf(mt[r], mt[r + n]);
-        float mloc;
-        {   // the other 32-lane half holds the other 16 keys of every 32-key block: v_permlane32_swap, no LDS round trip
-            const unsigned mb = __builtin_bit_cast(unsigned, mt[0]);
-            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-        }
-        if (__any((mloc - m_run) * a.c > 8.0f)) {          // deferred rescale (see attn_fwd8_kernel)
-            const float m_new = fmaxf(m_run, mloc);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * a.c);
-#pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-            m_run = m_new;
-        }
-        const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * a.c;
-        if (STAMP) { asm volatile("s_nop 0" ::"v"(mc) : "memory"); if (ts) ts[5] = __builtin_readcyclecounter(); }
-#pragma unroll
-        for (int sc = 0; sc < 2; ++sc) {
-            if (STAMP && sc == 1) { asm volatile("s_nop 0" ::"v"(oacc[0][0]) : "memory"); if (ts) ts[6] = __builtin_readcyclecounter(); }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[sc][r] = __builtin_amdgcn_exp2f(fmaf(s[sc][r], a.c, -mc));
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const int kk = 2 * sc + k2, rq = 2 * k2;
-                half8 pf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pf[e] = (half_t)s[sc][4 * rq + e];
-                    pf[4 + e] = (half_t)s[sc][4 * rq + 4 + e];
-                }
-#pragma unroll
-                for (int dt = 0; dt < C::DT; ++dt) {
-                    // keys 32 sc + 16 k2 + 4 g + {0..3} and the same + 8: the order in which S^T left the first MFMA
-                    union {
-                        half8 v;
-                        h4_t h[2];
-                    } vw;
-                    const uint8_t* vp = vt_ + (16 * kk) * VRB + dt * 64;
-                    vw.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp));
-                    vw.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp + 8 * VRB));
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vw.v, pf, oacc[dt], 0, 0, 0);
-                }
-            }
-        }
-    };
-    auto smpv_any = [&](const int kt) __attribute__((always_inline)) {
-        if (kt * 64 + 64 > kv_len) smpv(std::true_type{}, kt);     // wave-uniform: only the last tile can be ragged
-        else smpv(std::false_type{}, kt);
-    };
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        ts = nullptr;
-        if constexpr (STAMP) {   // [wg < 256][wave][tile < 16][8]: start, even work done, even barrier passed, odd work done, odd barrier passed
-            if (blockIdx.x < 256 && kt < 16 && lane == 0)
-                ts = reinterpret_cast<long long*>(a.o + (size_t)a.n_seq * a.o_seq_stride) + (((size_t)blockIdx.x * NW + wave) * 16 + kt) * 8;
-            if (ts) ts[0] = __builtin_readcyclecounter();
-        }
-        if (grp == 0) qk(kt);
-        else if (kt > 0) smpv_any(kt - 1);
-        if (STAMP) { asm volatile("s_nop 0" ::: "memory"); if (ts) ts[1] = __builtin_readcyclecounter(); }
-        wg_barrier();
-        if (STAMP) { if (ts) ts[2] = __builtin_readcyclecounter(); }
-        if (grp == 0) smpv_any(kt);
-        else qk(kt);
-        if (STAMP) { asm volatile("s_nop 0" ::: "memory"); if (ts) ts[3] = __builtin_readcyclecounter(); }
-        wg_barrier();
-        if (STAMP) { if (ts) ts[4] = __builtin_readcyclecounter(); }
-    }
-    if (grp == 1 && nkt > 0) smpv_any(nkt - 1);
-
-    constexpr int LD_T = D / 32, LD_R = D % 32;
-    constexpr int LD_G = (LD_R >> 2) & 1, LD_REG = (LD_R & 3) + 4 * (LD_R >> 3);
-    float l_run = oacc[LD_T][LD_REG];
-    l_run = __shfl(l_run, l31 + 32 * LD_G);
-    const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
-    if (q_ok) {
-        half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi * a.o_tok_stride + h * D;
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int d = dt * 32 + 8 * rg + 4 * g;
-                if (d < D) {
-                    half4 ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[dt][rg * 4 + e] * inv);
-                    *reinterpret_cast<half4*>(orow + d) = ov;
-                }
-            }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// attn_fwd32h_kernel: 32 queries per wave on 32x32x16 MFMAs (each 1-KiB K / V^T fragment read feeds 16384 MACs, twice
-// what the 16x16x32 form of attn_fwd16_kernel gets out of the LDS) AND four waves per SIMD: the online softmax runs per
-// 32-key half tile (16 score registers live instead of 32), one staging register set (the next tile is written to LDS
-// before the one after it is requested), V row-major with transpose reads -> <= 128 VGPRs, two 8-wave workgroups per CU.
-// ---------------------------------------------------------------------------
-template <int D, int ABLH = 0>
-__global__ __launch_bounds__(512, 4) void attn_fwd32h_kernel(AttnArgs a) {
-    constexpr int NW = 8;
-    using C = Att8Cfg<D, NW>;
-    constexpr int VRB = 192, VT = 64 * VRB;                 // row-major V image (see attn_fwd_pp_kernel)
-    constexpr int NTH = 64 * NW;
-    constexpr int NCH = 2 * C::KCH;
-    constexpr int SPT = (NCH + NTH - 1) / NTH;
+    constexpr int VRB = 192, VT = KT * VRB;                 // row-major V image (see attn_fwd_pp_kernel)
+    constexpr int KSL = C::KROW / 16, VSL = VRB / 16;       // 16-byte slots per row
+    constexpr int NKI = KSL * (KT / 64), NVI = VSL * (KT / 64);   // wave-instructions (64 slots) per K / V tile
+    constexpr int NI = NKI + NVI, IPW = (NI + NW - 1) / NW;
+    constexpr int PF = 2;
     static_assert(D * 2 + 2 <= VRB && C::DT * 64 <= VRB, "dims + ones column inside a row; every 32-dim tile readable");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1301,94 +1035,115 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32h_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     }
-    const int nkt = (kv_len + 63) / 64;
-    // staging: chunk c < KCH is K chunk c, else V chunk c - KCH
-    bool act[SPT];
-    int srow[SPT], sdst[SPT];
-    const half_t* ssrc[SPT];
+    const int nkt = (kv_len + KT - 1) / KT;
+    const int strideB = (int)a.kv_tok_stride * 2;
+    const unsigned nrec = kv_len > 0 ? (unsigned)(kv_len - 1) * (unsigned)strideB + D * 2 : 0u;
+    bool ok[IPW];
+    int voff[IPW];
 #pragma unroll
-    for (int i = 0; i < SPT; ++i) {
-        const int c = tid + i * NTH;
-        act[i] = c < NCH;
-        const bool isk = c < C::KCH;
-        const int cc = act[i] ? (isk ? c : c - C::KCH) : 0;
-        srow[i] = cc / C::CHD;
-        const int piece = cc - srow[i] * C::CHD;
-        ssrc[i] = (isk ? kbase : vbase) + (long)srow[i] * a.kv_tok_stride + piece * 8;
-        sdst[i] = isk ? srow[i] * C::KROW + piece * 16 : 2 * C::KTILE + srow[i] * VRB + piece * 16;
+    for (int i = 0; i < IPW; ++i) {
+        const int j = wave + NW * i;                       // wave-uniform instruction index: K tile first, then V
+        const bool isk = j < NKI;
+        const int slot = (isk ? j : j - NKI) * 64 + lane;
+        const int row = isk ? slot / KSL : slot / VSL;
+        const int piece = slot - row * (isk ? KSL : VSL);
+        ok[i] = j < NI && piece < C::CHD;
+        voff[i] = row * strideB + piece * 16;
     }
-    int4v sr[SPT];
-    auto load_stage = [&](int kt) __attribute__((always_inline)) {
-        const long t0 = (long)kt * 64 * a.kv_tok_stride;
-        const bool full = kt * 64 + 64 <= kv_len;
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        const unsigned t0 = (unsigned)kt * (unsigned)KT * (unsigned)strideB;
+        const int buf = kt & 1;
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            if (act[i]) {
-                if (full) sr[i] = *reinterpret_cast<const int4v*>(ssrc[i] + t0);
-                else {
-                    const int r_ = kt * 64 + srow[i] < kv_len ? srow[i] : kv_len - 1 - kt * 64;
-                    sr[i] = *reinterpret_cast<const int4v*>(ssrc[i] + t0 + (long)(r_ - srow[i]) * a.kv_tok_stride);
-                }
+        for (int i = 0; i < IPW; ++i) {
+            const int j = wave + NW * i;
+            if (j < NI) {
+                const bool isk = j < NKI;
+                const uint8_t* b = reinterpret_cast<const uint8_t*>(isk ? kbase : vbase) + t0;
+                // issued through asm: the builtin makes the compiler order every later ds_read behind the DMA (vmcnt(0)
+                // before the first MFMAs of the tile); the only consumer-side wait needed is the one in wg_barrier()
+                const unsigned long ba = (unsigned long)b;
+                const int4v rs = {(int)__builtin_amdgcn_readfirstlane((unsigned)ba),
+                                  (int)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                                  (int)__builtin_amdgcn_readfirstlane(nrec - t0), 0x00020000};
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem +
+                    (isk ? buf * KTB + j * 1024 : 2 * KTB + buf * VT + (j - NKI) * 1024));
+                if (ok[i])
+                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff[i]), "s"(rs)
+                                 : "memory", "m0");
             }
         }
     };
-    auto store_stage = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < SPT; ++i)
-            if (act[i]) *reinterpret_cast<int4v*>(smem + sdst[i] + buf * (sdst[i] < 2 * C::KTILE ? C::KTILE : VT)) = sr[i];
-    };
     auto wg_barrier = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    if (tid < 2 * 64 * 3) {   // pad columns of both V images: column D = 1.0, the rest 0
-        const int buf = tid / 192, r = (tid % 192) / 3, ch = tid % 3;
-        *reinterpret_cast<int4v*>(smem + 2 * C::KTILE + buf * VT + r * VRB + D * 2 + ch * 16) = int4v{ch == 0 ? 0x00003c00 : 0, 0, 0, 0};
+    for (int i = tid; i < 2 * KT * 3; i += 64 * NW) {   // pad columns of both V images: column D = 1.0, the rest 0
+        const int r = i / 3, ch = i % 3;                 // r runs over the rows of both images (contiguous)
+        *reinterpret_cast<int4v*>(smem + 2 * KTB + r * VRB + D * 2 + ch * 16) = int4v{ch == 0 ? 0x00003c00 : 0, 0, 0, 0};
     }
-    if (nkt > 0) {
-        load_stage(0);
-        store_stage(0);
-        if (nkt > 1) load_stage(1);
-    }
+    if (nkt > 0) issue(0);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) asm volatile("" ::"v"(qf[ks]));   // the compiler's own wait for the Q loads goes HERE, not
+                                                                          // (as vmcnt(0), stalling on the DMA) into the loop
     wg_barrier();
     const int vtr0 = (4 * g + ((lane & 15) >> 2)) * VRB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
     auto tile = [&](auto rag_tag, const int kt) __attribute__((always_inline)) {
         constexpr bool RAG = decltype(rag_tag)::value;
-        const uint8_t* kt_ = smem + (kt & 1) * C::KTILE + l31 * C::KROW;
-        const uint8_t* vt_ = smem + 2 * C::KTILE + (kt & 1) * VT + vtr0;
+        const uint8_t* kt_ = smem + (kt & 1) * KTB + l31 * C::KROW;
+        const uint8_t* vt_ = smem + 2 * KTB + (kt & 1) * VT + vtr0;
+        if (!(ABLD & 1) && kt + 1 < nkt) issue(kt + 1);     // into the buffers whose last readers passed the previous barrier
 #pragma unroll
-        for (int sc = 0; sc < 2; ++sc) {
+        for (int sc = 0; sc < KT / 32; ++sc) {
             float16v s;
             const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            union VF {
+                half8 v;
+                h4_t h[2];
+            };
+            VF vf[2 * C::DT];
+            auto rdv = [&](int idx) __attribute__((always_inline)) {      // V^T fragment idx = k2 * DT + dt of this half tile
+                const int kk = 2 * sc + idx / C::DT, dt = idx % C::DT;
+                const uint8_t* vp = vt_ + (16 * kk) * VRB + dt * 64;
+                vf[idx].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp));
+                vf[idx].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp + 8 * VRB));
+            };
+            // fragment reads run PF ahead of the MFMAs in ONE sequence (K fragments 0..KS-1, then the V^T fragments: the
+            // first of those fly under the softmax); sched_barrier pins the order - left alone the scheduler sinks every
+            // read next to its MFMA and exposes one LDS latency per MFMA
+            half8 kf[C::KS];
+            auto rdc = [&](int n) __attribute__((always_inline)) {
+                if (n < C::KS) {
+                    const int d0 = n * 16 + 8 * g;
+                    kf[n] = *reinterpret_cast<const half8*>(kt_ + sc * 32 * C::KROW + (d0 < D ? d0 : 0) * 2);
+                } else if (n - C::KS < 2 * C::DT) rdv(n - C::KS);
+            };
+#pragma unroll
+            for (int n = 0; n < PF; ++n) rdc(n);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
-                const int d0 = ks * 16 + 8 * g;
-                const half8 kf = *reinterpret_cast<const half8*>(kt_ + sc * 32 * C::KROW + (d0 < D ? d0 : 0) * 2);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
-            }
-            if (sc == 0) {   // next tile into the other buffers (their last readers passed the previous barrier)
-                if (!(ABLH & 2) && kt + 1 < nkt) store_stage((kt + 1) & 1);
-                if (!(ABLH & 1) && kt + 2 < nkt) load_stage(kt + 2);
+                rdc(ks + PF);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (RAG) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kt * 64 + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g >= kv_len) s[r] = -INFINITY;
+                    if (kt * KT + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g >= kv_len) s[r] = -INFINITY;
             }
-            float mt[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mt[r] = s[r];
-#pragma unroll
-            for (int n = 8; n >= 1; n >>= 1)
-#pragma unroll
-                for (int r = 0; r < n; ++r) mt[r] = fmaxf(mt[r], mt[r + n]);
             float mloc;
             {
-                const unsigned mb = __builtin_bit_cast(unsigned, mt[0]);
+                float mx;   // v_max3 chain in asm: fmaxf() would canonicalise every MFMA result first (one extra v_max each)
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[r]), "v"(s[r + 1]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[15]));
+                const unsigned mb = __builtin_bit_cast(unsigned, mx);
                 const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-                mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(sw[0]), "v"(sw[1]));
             }
             if (__any((mloc - m_run) * a.c > 8.0f)) {
                 const float m_new = fmaxf(m_run, mloc);
@@ -1401,34 +1156,31 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32h_kernel(AttnArgs a) {
                 m_run = m_new;
             }
             const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * a.c;
+            half8 pf[2];
+            {
+                typedef float float2v __attribute__((ext_vector_type(2)));
+                const float2v cc2 = {a.c, a.c}, mm2 = {-mc, -mc};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], a.c, -mc));
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const int kk = 2 * sc + k2, rq = 2 * k2;
-                half8 pf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pf[e] = (half_t)s[4 * rq + e];
-                    pf[4 + e] = (half_t)s[4 * rq + 4 + e];
-                }
-#pragma unroll
-                for (int dt = 0; dt < C::DT; ++dt) {
-                    union {
-                        half8 v;
-                        h4_t h[2];
-                    } vw;
-                    const uint8_t* vp = vt_ + (16 * kk) * VRB + dt * 64;
-                    vw.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp));
-                    vw.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp + 8 * VRB));
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vw.v, pf, oacc[dt], 0, 0, 0);
+                for (int r = 0; r < 16; r += 2) {
+                    float2v t = {s[r], s[r + 1]};
+                    t = __builtin_elementwise_fma(t, cc2, mm2);      // v_pk_fma_f32
+                    pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(t[0]);
+                    pf[r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t[1]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int idx = 0; idx < 2 * C::DT; ++idx) {
+                rdc(C::KS + idx + PF);
+                const int dt = idx % C::DT;
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx].v, pf[idx / C::DT], oacc[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (!(ABLH & 4)) wg_barrier();
+        if (!(ABLD & 4)) wg_barrier();
     };
     {
-        const int nfull = kv_len / 64;
+        const int nfull = kv_len / KT;
         int kt = 0;
         for (; kt < nfull; ++kt) tile(std::false_type{}, kt);
         if (kt < nkt) tile(std::true_type{}, kt);
@@ -1455,288 +1207,29 @@ __global__ __launch_bounds__(512, 4) void attn_fwd32h_kernel(AttnArgs a) {
     }
 }
 
-template <int D>
-static int launch_attn32h(const AttnArgs& a, hipStream_t st) {
-    constexpr int LDS = 2 * Att8Cfg<D, 8>::KTILE + 2 * 64 * 192;
-    auto k = attn_fwd32h_kernel<D>;
-    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);  // once
-    if (e != hipSuccess) {
-        g_vq_last_hip_error = (int)e;
-        return VQ_ELAUNCH;
-    }
-    const int nqt = (a.Lq + 255) / 256, G = a.n_seq * a.H;
-    hipLaunchKernelGGL(k, dim3(8 * ((G + 7) / 8) * nqt), dim3(512), LDS, st, a);
-    return vq_check_launch();
-}
-
-// ---------------------------------------------------------------------------
-// attn_fwd16_kernel: flash attention for long sequences at FOUR waves per SIMD.
-// What the 8-wave kernels above showed (tools/attn_stamps.py, rocprofv3 --pmc): a wave issues roughly one instruction
-// per 5 cycles whatever its neighbours do (290 instructions per 64-key tile in ~4100 cycles, SQ_WAIT_ANY 55 %), and
-// with 210+ VGPRs only two waves fit a SIMD, both in the same phase of the tile - putting the two in opposite phases
-// (attn_fwd_pp_kernel) just moved the waiting around.  The lever is occupancy: here a wave owns 16 queries instead of
-// 32 (16x16x32 MFMAs: O^T 20 + S^T 16 + q 12 accumulator / operand registers instead of 48 + 32 + 20), fits 128
-// VGPRs, and a 1024-thread workgroup puts four waves on every SIMD behind ONE barrier per key tile.
-//   S^T[key][q] = K Q^T : A = K rows (16 keys x 32 dims per MFMA, ds_read_b128 from the row-major K tile)
-//   O^T[dim][q] += V^T P^T : A = V^T (16 dims x 32 keys) by the LDS transpose read (ds_read_b64_tr_b16) of the
-//       ROW-major V tile - V is staged with plain 16-byte writes like K, no transposing write pass;
-//       B = P^T: the k-slot order of a 32-key step is (g4, e) <-> key (2 kp + (e >> 2)) * 16 + 4 g4 + (e & 3), i.e. the
-//       two S^T accumulator quads the lane already holds (exp2, cvt, no shuffle; attn_cross_reg_kernel's layout).
-// V rows are 160 bytes (40 dwords: the 8 key rows a 32-lane transpose read touches fall on 8 disjoint 8-bank runs);
-// column D of every V row is 1.0, so dim-block 4 of O^T carries the softmax row sums.  Deferred rescale as above.
-// ---------------------------------------------------------------------------
-// ABL16 (profiling only, wrong results): 1 no global loads after the prologue, 2 no staging LDS writes, 4 no barrier,
-// 8 no exp, 16 no P.V (reads + MFMAs), 32 no QK^T (reads + MFMAs)
-template <int D, int NWV, int ABL16 = 0>
-__global__ __launch_bounds__(64 * NWV, 4) void attn_fwd16_kernel(AttnArgs a) {
-    constexpr int KS = (D + 31) / 32;                       // 32-dim k-steps of QK^T
-    constexpr int DB = (D + 1 + 15) / 16;                   // 16-dim blocks of O^T incl. the ones column
-    constexpr int CHD = D / 8;                              // 16-byte chunks per key row
-    constexpr int KRB = (CHD | 1) * 16, VRB = 160;
-    constexpr int KT = 64 * KRB, VT = 64 * VRB;
-    constexpr int NTH = 64 * NWV;
-    constexpr int NCH = 2 * 64 * CHD;                       // K + V chunks of a 64-key tile
-    constexpr int SPT = (NCH + NTH - 1) / NTH;
-    static_assert(D % 8 == 0 && D * 2 + 16 <= VRB && DB * 32 <= VRB, "row geometry");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* const kimg = smem;
-    uint8_t* const vimg = smem + 2 * KT;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lq = lane & 15, g4 = lane >> 4;
-    int qt, h, seq;
-    {   // XCD-aware (sequence, head, query tile) placement: see attn_fwd8_kernel
-        const int nqt = (a.Lq + 16 * NWV - 1) / (16 * NWV);
-        const int G = a.n_seq * a.H;
-        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-        const int q8 = G / 8, r8 = G % 8;
-        const int gbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-        const int gcount = xcd < r8 ? q8 + 1 : q8;
-        const int pl = idx / nqt;
-        if (pl >= gcount) return;
-        const int pair = gbase + pl;
-        qt = idx - pl * nqt;
-        seq = pair / a.H;
-        h = pair - seq * a.H;
-    }
-    const int kv_len = a.Lk;
-    const half_t* kbase = a.k + (long)seq * a.kv_seq_stride + h * D;
-    const half_t* vbase = a.v + (long)seq * a.kv_seq_stride + h * D;
-    const int qi = qt * (16 * NWV) + wave * 16 + lq;
-    const bool q_ok = qi < a.Lq;
-    half8 qf[KS];
-    {
-        const half_t* qrow = a.q + (long)seq * a.q_seq_stride + (long)(q_ok ? qi : a.Lq - 1) * a.q_tok_stride + h * D;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int d0 = ks * 32 + 8 * g4;
-            if (d0 < D) qf[ks] = *reinterpret_cast<const half8*>(qrow + d0);
-            else
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)0.f;
-        }
-    }
-    float4v oacc[DB];
-#pragma unroll
-    for (int dt = 0; dt < DB; ++dt) oacc[dt] = float4v{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY;
-    const int nkt = (kv_len + 63) / 64;
-
-    // ---- staging: chunk c < 64 * CHD is K chunk c, else V chunk c - 64 * CHD (row = key, 16-byte piece of its D dims)
-    bool act[SPT];
-    int srow[SPT], sdst[SPT];
-    const half_t* ssrc[SPT];
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) {
-        const int c = tid + i * NTH;
-        act[i] = c < NCH;
-        const bool isk = c < 64 * CHD;
-        const int cc = act[i] ? (isk ? c : c - 64 * CHD) : 0;
-        srow[i] = cc / CHD;
-        const int piece = cc - srow[i] * CHD;
-        ssrc[i] = (isk ? kbase : vbase) + (long)srow[i] * a.kv_tok_stride + piece * 8;
-        sdst[i] = isk ? srow[i] * KRB + piece * 16 : 2 * KT + srow[i] * VRB + piece * 16;
-    }
-    int4v sr[SPT];
-    auto load_stage = [&](int kt) __attribute__((always_inline)) {
-        const long t0 = (long)kt * 64 * a.kv_tok_stride;
-        const bool full = kt * 64 + 64 <= kv_len;           // wave-uniform
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            if (act[i]) {
-                if (full) sr[i] = *reinterpret_cast<const int4v*>(ssrc[i] + t0);
-                else {                                      // ragged last tile: rows past the end re-read the last key
-                    const int r_ = kt * 64 + srow[i] < kv_len ? srow[i] : kv_len - 1 - kt * 64;
-                    sr[i] = *reinterpret_cast<const int4v*>(ssrc[i] + t0 + (long)(r_ - srow[i]) * a.kv_tok_stride);
-                }
-            }
-        }
-    };
-    auto store_stage = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < SPT; ++i)
-            if (act[i]) *reinterpret_cast<int4v*>(smem + sdst[i] + buf * (sdst[i] < 2 * KT ? KT : VT)) = sr[i];
-    };
-    auto wg_barrier = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS traffic of this wave done; global loads stay in flight
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    // pad chunk of every V row (bytes 2 D .. 2 D + 15, never touched by the staging stores): column D = 1.0, rest 0
-    if (tid < 2 * 64)
-        *reinterpret_cast<int4v*>(vimg + (tid >> 6) * VT + (tid & 63) * VRB + D * 2) = int4v{0x00003c00, 0, 0, 0};
-    if (nkt > 0) {
-        load_stage(0);
-        store_stage(0);
-        if (nkt > 1) load_stage(1);
-    }
-    wg_barrier();
-
-    const int kfr0 = lq * KRB;                               // K fragment row of this lane inside a 16-key block
-    const int vtr0 = (4 * g4 + (lq >> 2)) * VRB + (lq & 3) * 8;   // transpose-read base: key row 4 g4 + lq / 4, dims 4 (lq & 3)
-    auto tile = [&](auto rag_tag, const int kt) __attribute__((always_inline)) {
-        constexpr bool RAG = decltype(rag_tag)::value;
-        const uint8_t* kt_ = kimg + (kt & 1) * KT + kfr0;
-        const uint8_t* vt_ = vimg + (kt & 1) * VT + vtr0;
-        float4v sc[4];
-        // ---- S^T = K Q^T: k-step outer, key block inner (four independent accumulator chains)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int d0 = ks * 32 + 8 * g4;
-            // lanes whose dims lie past D read dims 0..7 of their key row (finite data) against a zero q fragment
-            const int dof = (d0 < D ? d0 : 0) * 2;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                if (ABL16 & 32) {
-                    sc[kb] = float4v{(float)qf[ks][0], (float)qf[ks][1], (float)kb, (float)dof};
-                    continue;
-                }
-                const half8 kf = *reinterpret_cast<const half8*>(kt_ + kb * 16 * KRB + dof);
-                sc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], ks == 0 ? float4v{0.f, 0.f, 0.f, 0.f} : sc[kb], 0, 0, 0);
-            }
-        }
-        // ---- stage the next tile (its buffer had its last reader before the previous barrier), request the one after
-        if (!(ABL16 & 2) && kt + 1 < nkt) store_stage((kt + 1) & 1);
-        if (!(ABL16 & 1) && kt + 2 < nkt) load_stage(kt + 2);
-        // ---- online softmax (deferred rescale)
-        if constexpr (RAG) {
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 64 + kb * 16 + 4 * g4 + r >= kv_len) sc[kb][r] = -INFINITY;
-        }
-        float mloc = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
-                           fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
-        mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(sc[2][0], sc[2][1]), fmaxf(sc[2][2], sc[2][3])),
-                                 fmaxf(fmaxf(sc[3][0], sc[3][1]), fmaxf(sc[3][2], sc[3][3]))));
-        {   // max over the four 16-lane rows (same query, other keys): VALU lane swaps, no LDS round trip (the LDS queue
-            // is the busiest unit of this kernel)
-            unsigned mb = __builtin_bit_cast(unsigned, mloc);
-            auto s16 = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
-            mb = __builtin_bit_cast(unsigned, mloc);
-            auto s32 = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, s32[0]), __builtin_bit_cast(float, s32[1]));
-        }
-        if (__any((mloc - m_run) * a.c > 8.0f)) {
-            const float m_new = fmaxf(m_run, mloc);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * a.c);
-#pragma unroll
-            for (int dt = 0; dt < DB; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
-            m_run = m_new;
-        }
-        const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * a.c;
-        // ---- P = exp2(s c - m c), O^T += V^T P^T per 32-key step
-#pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {
-            half8 pf;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                pf[e] = (ABL16 & 8) ? (half_t)fmaf(sc[2 * kp + (e >> 2)][e & 3], a.c, -mc)
-                                    : (half_t)__builtin_amdgcn_exp2f(fmaf(sc[2 * kp + (e >> 2)][e & 3], a.c, -mc));
-#pragma unroll
-            for (int dt = 0; dt < DB; ++dt) {
-                if (ABL16 & 16) {
-                    oacc[dt][0] += (float)pf[dt];
-                    continue;
-                }
-                union {
-                    half8 v;
-                    h4_t h[2];
-                } vw;
-                const uint8_t* vp = vt_ + (2 * kp) * 16 * VRB + dt * 32;
-                vw.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp));
-                vw.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp + 16 * VRB));
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vw.v, pf, oacc[dt], 0, 0, 0);
-            }
-        }
-        if (!(ABL16 & 4)) wg_barrier();
-    };
-    {
-        const int nfull = kv_len / 64;
-        int kt = 0;
-        for (; kt < nfull; ++kt) tile(std::false_type{}, kt);
-        if (kt < nkt) tile(std::true_type{}, kt);
-    }
-
-    // softmax row sum = row D of O^T = block D / 16, row D % 16 = 4 g4 + r
-    constexpr int LB = D / 16, LR = D % 16;
-    float l_run = oacc[LB][LR & 3];
-    l_run = __shfl(l_run, 16 * (LR >> 2) + lq);
-    const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
-    if (q_ok) {
-        half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi * a.o_tok_stride + h * D;
-#pragma unroll
-        for (int dt = 0; dt < DB; ++dt) {
-            const int d0 = dt * 16 + 4 * g4;
-            if (d0 < D) {
-                half4 ov;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(oacc[dt][r] * inv);
-                *reinterpret_cast<half4*>(orow + d0) = ov;
-            }
-        }
-    }
-}
-
-template <int D>
-static int launch_attn16(const AttnArgs& a, hipStream_t st) {
-    constexpr int LDS = 2 * 64 * (((D / 8) | 1) * 16) + 2 * 64 * 160;
-    static const bool w8 = getenv("VQ_ATTN16_W8") != nullptr;      // measurement switch: two 8-wave workgroups per CU
-    const int G = a.n_seq * a.H;
-    if (w8) {
-        auto k8 = attn_fwd16_kernel<D, 8>;
-        static hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)e8;
-        hipLaunchKernelGGL(k8, dim3(8 * ((G + 7) / 8) * ((a.Lq + 127) / 128)), dim3(512), LDS, st, a);
-        return vq_check_launch();
-    }
-    constexpr int NWV = 16;
-    if (D == 72) {
-        static const int abl = getenv("VQ_ATTN16_ABL") ? atoi(getenv("VQ_ATTN16_ABL")) : 0;
+template <int D, int NW = 8, int KT = 64>
+static int launch_attn32d(const AttnArgs& a, hipStream_t st) {
+    constexpr int LDS = 2 * (KT / 64) * Att8Cfg<D, 8>::KTILE + 2 * KT * 192;
+    auto k = attn_fwd32d_kernel<D, 0, NW, KT>;
+    const int nqt = (a.Lq + 32 * NW - 1) / (32 * NW), G = a.n_seq * a.H;
+#ifdef VQ_LAB_ABLATIONS   // profiling builds only (wrong results by design); never defined for the product library
+    if (D == 72 && NW == 8) {
+        static const int abl = getenv("VQ_ATTN32_ABL") ? atoi(getenv("VQ_ATTN32_ABL")) : 0;
         if (abl) {
-            auto ka = abl == 1 ? attn_fwd16_kernel<72, 16, 1> : abl == 2 ? attn_fwd16_kernel<72, 16, 2> : abl == 3 ? attn_fwd16_kernel<72, 16, 3>
-                    : abl == 4 ? attn_fwd16_kernel<72, 16, 4> : abl == 8 ? attn_fwd16_kernel<72, 16, 8> : abl == 16 ? attn_fwd16_kernel<72, 16, 16>
-                    : abl == 32 ? attn_fwd16_kernel<72, 16, 32> : attn_fwd16_kernel<72, 16, 7>;
+            auto ka = abl == 1 ? attn_fwd32d_kernel<72, 1> : abl == 4 ? attn_fwd32d_kernel<72, 4> : attn_fwd32d_kernel<72, 5>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            hipLaunchKernelGGL(ka, dim3(8 * ((G + 7) / 8) * ((a.Lq + 255) / 256)), dim3(1024), LDS, st, a);
+            hipLaunchKernelGGL(ka, dim3(8 * ((G + 7) / 8) * nqt), dim3(512), LDS, st, a);
             return vq_check_launch();
         }
     }
-    auto k = attn_fwd16_kernel<D, NWV>;
+#endif
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);  // once
     if (e != hipSuccess) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
     }
-    const int nqt = (a.Lq + 16 * NWV - 1) / (16 * NWV);
-    hipLaunchKernelGGL(k, dim3(8 * ((G + 7) / 8) * nqt), dim3(64 * NWV), LDS, st, a);
+    hipLaunchKernelGGL(k, dim3(8 * ((G + 7) / 8) * nqt), dim3(64 * NW), LDS, st, a);
     return vq_check_launch();
 }
 
@@ -1927,6 +1420,7 @@ template <int D, int NW, int NQ = 1>
 static int launch_attn8(const AttnArgs& a, hipStream_t st) {
     using C = Att8Cfg<D, NW>;
     auto k = attn_fwd8_kernel<D, NW, 0, NQ>;
+#ifdef VQ_LAB_ABLATIONS   // profiling builds only (wrong results by design); never defined for the product library
     if (D == 72 && NW == 8 && NQ == 1) {               // profiling ablations (VQ_ATTN_ABL)
         static const int abl = getenv("VQ_ATTN_ABL") ? atoi(getenv("VQ_ATTN_ABL")) : 0;
         if (abl) {
@@ -1940,6 +1434,7 @@ static int launch_attn8(const AttnArgs& a, hipStream_t st) {
             return vq_check_launch();
         }
     }
+#endif
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);  // once
     if (e != hipSuccess) {
@@ -1953,32 +1448,6 @@ static int launch_attn8(const AttnArgs& a, hipStream_t st) {
 }
 
 template <int D>
-static int launch_attn_pp(const AttnArgs& a, hipStream_t st) {
-    struct C {
-        enum { LDS = 2 * Att8Cfg<D, 8>::KTILE + 2 * 64 * 192 };
-    };
-    auto k = attn_fwd_pp_kernel<D>;
-    if (D == 72) {
-        static const bool stamp = getenv("VQ_ATTN_STAMP") != nullptr;   // tools/attn_stamps.py (stamps behind the output)
-        if (stamp) {
-            auto ks = attn_fwd_pp_kernel<72, true>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-            hipLaunchKernelGGL(ks, dim3(8 * ((a.n_seq * a.H + 7) / 8) * ((a.Lq + 255) / 256)), dim3(512), C::LDS, st, a);
-            return vq_check_launch();
-        }
-    }
-    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);  // once
-    if (e != hipSuccess) {
-        g_vq_last_hip_error = (int)e;
-        return VQ_ELAUNCH;
-    }
-    const int nqt = (a.Lq + 255) / 256, G = a.n_seq * a.H;
-    hipLaunchKernelGGL(k, dim3(8 * ((G + 7) / 8) * nqt), dim3(512), C::LDS, st, a);
-    return vq_check_launch();
-}
-
-template <int D>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
     // second-generation kernel for long key sequences; short ones (cross attention: <= 2 key tiles, where the
     // per-workgroup prologue dominates) and short query sequences keep the first kernel.  VQ_ATTN_V1 forces it.
@@ -1988,13 +1457,10 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     if (D == 72 && !old_kernel && !no_reg && a.Lk > 0 && a.Lk <= 128 && a.H % 8 == 0 && a.Lq >= 64) return launch_cross_reg(a, st);
     if (!old_kernel && !a.kv_off && a.Lk > 128 && a.Lq >= 96)
     {
-        static const bool two = getenv("VQ_ATTN_NQ2") != nullptr;      // measurement switch
-        static const bool no_pp = getenv("VQ_ATTN_PP") && atoi(getenv("VQ_ATTN_PP")) == 0;   // measurement switch
-        static const int which = getenv("VQ_ATTN_LONG") ? atoi(getenv("VQ_ATTN_LONG")) : 16;   // measurement switch: 8 | 16 | 2 (pp)
-        if (which == 32 && a.Lq >= 192) return launch_attn32h<D>(a, st);            // 32 queries per wave, half-tile softmax, 4 waves per SIMD
-        if (which == 16 && D <= 72 && a.Lq >= 192) return launch_attn16<D>(a, st);   // four waves per SIMD, 16 queries per wave
-        if (which == 2 && !no_pp && a.Lq >= 192) return launch_attn_pp<D>(a, st);     // opposite-phase SIMD partners
-        if (two && a.Lq >= 192) return launch_attn8<D, 4, 2>(a, st);
+        // long query sequences: 32 queries per wave, LDS-DMA tiles, four waves per SIMD (attn_fwd32d_kernel; its buffer
+        // loads carry 32-bit byte offsets).  VQ_ATTN_LONG=8 keeps the previous generation for A/B measurements.
+        static const bool gen8 = getenv("VQ_ATTN_LONG") && atoi(getenv("VQ_ATTN_LONG")) == 8;
+        if (!gen8 && a.Lq >= 192 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31)) return launch_attn32d<D>(a, st);
         return a.Lq >= 192 ? launch_attn8<D, 8>(a, st) : launch_attn8<D, 4>(a, st);
     }
     using C = AttCfg<D>;

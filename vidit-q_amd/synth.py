@@ -198,7 +198,7 @@ def synthetic_prompts(n: int, device, model_max_length=120, caption_channels=409
     g = torch.Generator().manual_seed(seed)
     y = (torch.randn(n, 2, 1, model_max_length, caption_channels, generator=g) * 0.1).half()
     gl = torch.Generator().manual_seed(seed + 1)
-    lens = torch.randint(20, model_max_length + 1, (n,), generator=gl)
+    lens = torch.randint(min(20, max(1, model_max_length // 2)), model_max_length + 1, (n,), generator=gl)
     mask = (torch.arange(model_max_length)[None, :] < lens[:, None]).to(torch.int64)
     return dict(y=y.to(device), mask=mask.to(device)), lens.tolist()
 
