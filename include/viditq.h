@@ -71,6 +71,8 @@ int vq_last_hip_error(void);
  * add_rows nullable [n_add, C] fp16 added to row r as add_rows[(r % n_tok) / add_div]
  * s        nullable [C] fp32 smooth-quant channel scale; x is DIVIDED by s in-kernel
  *          (correctly rounded division, bit-exact with the reference's x / s)
+ * s_rcp    nullable [C] fp32 RN(1 / s) from vq_smooth_reciprocal (only when it reported 0 bad channels): the
+ *          same quotient in 3 instead of ~12 instructions per element; without it the kernels divide the IEEE way
  * xq       [B*n_tok, Kp] int8 (code - cx, cx = 128 when n_bits==8 else 0)
  * sx       [B*n_tok] fp32 delta      zx [B*n_tok] int32 (zp - cx)
  * R        [B*n_tok] int32           zpf nullable [B*n_tok] fp32 (raw zero point)
@@ -79,7 +81,7 @@ int vq_last_hip_error(void);
  *          when given, no min/max is taken
  * status   nullable device int32 (bit VQ_ST_EPSFILL or-ed in)
  */
-int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, const float* s,
+int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, const float* s, const float* s_rcp,
                 int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf,
                 const float* delta_in, const float* zp_in, int n_param,
                 int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
@@ -91,8 +93,8 @@ int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, con
  * exp/rcp run under this HBM-bound kernel instead of the MFMA-bound GEMM epilogue.  GELU output is rounded to fp16
  * before quantization (the activation dtype of the reference pipeline).  B must be 1 (VQ_EUNSUP otherwise: token
  * scales shared over a batch need the two-pass generic kernel).  Outputs as vq_rowquant. */
-int vq_gelu_rowquant(const void* x, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, int B, int n_tok,
-                     int C, int Kp, int n_bits, int32_t* status, void* stream);
+int vq_gelu_rowquant(const void* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx, int32_t* R,
+                     int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
 
 /* Same, fused with LayerNorm(eps, no affine) + AdaLN modulate:
  *   x_m = LN(x) * (1 + scale[b]) + shift[b]       (stdit.py:100-103,124)
@@ -102,9 +104,26 @@ int vq_gelu_rowquant(const void* x, const float* s, int8_t* xq, float* sx, int32
  * xm_out nullable [B*n_tok, C] fp16: the modulated activation itself.
  */
 int vq_ln_modulate_rowquant(const void* x, const float* shift, const float* scale, float ln_eps,
-                            int n_out, const float* const* s, int8_t* const* xq, float* const* sx,
+                            int n_out, const float* const* s, const float* const* s_rcp, int8_t* const* xq, float* const* sx,
                             int32_t* const* zx, int32_t* const* R, void* xm_out,
                             int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
+
+/* n_out (1..3) smoothed per-token quantizers of the SAME input x [n_tok, C] (B == 1) in one launch: output j is
+ * vq_rowquant(x, s[j], s_rcp[j]).  The q / k / v activation quantizers of a plan that balances each Linear against
+ * its own weight (quant_layer.py:136-160), where no LayerNorm precedes them (temporal attention, stdit.py:112-118).
+ * Arrays are HOST arrays of device pointers, reciprocals mandatory.  Shapes outside the reciprocal-form kernel
+ * (C % 128, 768 <= C <= 1280, Kp == C, n_tok >= 2) return VQ_EUNSUP - call vq_rowquant per output instead. */
+int vq_rowquant_smooth_multi(const void* x, int n_out, const float* const* s, const float* const* s_rcp,
+                             int8_t* const* xq, float* const* sx, int32_t* const* zx, int32_t* const* R,
+                             int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
+
+/* Reciprocal of a smooth-quant channel scale for the s_rcp arguments above: r[c] = RN(1 / s[c]); *n_bad (device int32,
+ * zeroed by the caller) counts the channels for which the reciprocal form of x / s is not guaranteed bit-exact
+ * (s not a positive normal number, significand all ones, reciprocal not normal): pass s_rcp only when it stays 0.
+ * Replaces nothing in the reference - it is how `x / s` (quant_layer.py:140) is evaluated here. */
+int vq_smooth_reciprocal(const float* s, float* r, int n, int32_t* n_bad, void* stream);
+/* Test hook: fast[i] = a[i] / b[i] through the reciprocal form, exact[i] = the IEEE quotient. */
+int vq_smooth_div_check(const float* a, const float* b, float* fast, float* exact, long n, void* stream);
 
 /* Quantize->dequantize (the reference's fake-quant result), exact incl. the
  * global eps-fill rule; the operator behind BaseQuantizer.forward for
@@ -161,6 +180,16 @@ int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32
 int vq_gemm_i8_batched(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R, const void* wq,
                        const float* sw, const int32_t* zw, const int32_t* cs, const float* bias, void* out,
                        int nbatch, int M, int N, int K, int Kp, int w_bits, void* stream);
+
+/* ngroups (1..3) independent Linears of ONE shape in one grid: out_g [M, N] = dequant(xq_g . wq_g^T) + bias_g at
+ * out + g * N, row pitch ldo >= ngroups * N (the q | k | v column blocks of one buffer).  For the plans that balance
+ * q / k / v each against its own weight (quant_layer.py:136-160: three smoothing vectors, hence three quantized copies
+ * of the shared input, stdit_quant_layer.py:96,187,304 applied per layer): what the reference runs as three F.linear
+ * calls.  Arrays are HOST arrays of device pointers; bias nullable (and each entry nullable).  No fused epilogue. */
+int vq_gemm_i8_grouped(int ngroups, const int8_t* const* xq, const float* const* sx, const int32_t* const* zx,
+                       const int32_t* const* R, const void* const* wq, const float* const* sw,
+                       const int32_t* const* zw, const int32_t* const* cs, const float* const* bias, void* out,
+                       int ldo, int M, int N, int K, int Kp, int w_bits, void* stream);
 
 /* ---- fp16 attention (fp32 online softmax) -----------------------------------
  * Replaces flash_attn_func / the softmax branch of Attention.forward

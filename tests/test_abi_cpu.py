@@ -36,14 +36,14 @@ def test_argument_validation_without_gpu():
     import viditq_amd  # noqa: F401
     from viditq_amd import _lib
     lib = _lib.load()
-    assert lib.vq_rowquant(None, None, 0, 1, None, None, None, None, None, None, None, None, 0,
+    assert lib.vq_rowquant(None, None, 0, 1, None, None, None, None, None, None, None, None, None, 0,
                            1, 1, 8, 128, 8, None, None) == -1
     assert lib.vq_gemm_i8(None, None, None, None, None, None, None, None, None, None, 0, None, None,
                           0, 1, 1, 1, 128, 8, 0, 0, None) == -1
     one = ctypes.c_void_p(16)  # non-null dummy; rejected by the shape checks before any dereference
-    assert lib.vq_rowquant(one, None, 0, 1, None, one, one, one, one, None, None, None, 0,
+    assert lib.vq_rowquant(one, None, 0, 1, None, None, one, one, one, one, None, None, None, 0,
                            1, 1, 12, 128, 8, None, None) == -2
-    assert lib.vq_rowquant(one, None, 0, 1, None, one, one, one, one, None, None, None, 0,
+    assert lib.vq_rowquant(one, None, 0, 1, None, None, one, one, one, one, None, None, None, 0,
                            1, 1, 8, 128, 9, None, None) == -4
     assert lib.vq_attn_temporal(one, one, one, one, 1, 17, 4, 4, 72, 8, 8, 1.0, None) == -2
 

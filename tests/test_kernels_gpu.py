@@ -233,13 +233,17 @@ def test_gemm_full_tile_property_linearity(ops, dev):
 
 
 # ----------------------------------------------------------------------------- LN + modulate + quant
-@pytest.mark.parametrize("B,n_tok,C,nout", [(1, 64, 64, 1), (2, 32, 1152, 3)])
-def test_ln_modulate_rowquant(ops, dev, B, n_tok, C, nout):
+@pytest.mark.parametrize("B,n_tok,C,nout,all_smooth", [(1, 64, 64, 1, False), (2, 32, 1152, 3, False),
+                                                       (1, 131, 1152, 3, True), (1, 64, 1152, 1, True)])
+def test_ln_modulate_rowquant(ops, dev, B, n_tok, C, nout, all_smooth):
+    """all_smooth at B == 1, C == 1152 is the W4A8 q/k/v (and fc1) hand-over: smooth_rowquant_half_kernel."""
     x = h16(B, n_tok, C, scale=2.0, seed=31)
     shift = h16(B, C, scale=0.3, seed=32).float()
     scale = h16(B, C, scale=0.3, seed=33).float()
     smooth = [None] + [(torch.rand(C, generator=torch.Generator().manual_seed(40 + j)) + 0.5).float()
                        for j in range(nout - 1)]
+    if all_smooth:
+        smooth = [(torch.rand(C, generator=torch.Generator().manual_seed(50 + j)) + 0.5).float() for j in range(nout)]
     xm = fq.t2i_modulate(fq.layernorm_noaffine(x.float()), shift[:, None, :], scale[:, None, :])
     outs, xm_got = ops.ln_modulate_rowquant(x.to(dev), shift.to(dev), scale.to(dev), 1e-6,
                                             smooth=[None if s is None else s.to(dev) for s in smooth], want_xm=True)
@@ -256,6 +260,87 @@ def test_ln_modulate_rowquant(ops, dev, B, n_tok, C, nout):
         got_dq = (got.float() - (qa.zx.cpu().reshape(B, n_tok, 1) + 128)) * qa.sx.cpu().reshape(B, n_tok, 1)
         assert rel_l2(got_dq, dq) < 2e-3
         assert torch.allclose(qa.sx.cpu().reshape(B, n_tok)[0], delta.reshape(-1), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- smooth-quant division by reciprocal
+def _same_quotients(fast, exact):
+    """bit-identical, except that -0 / s comes out as +0 (no quantizer output depends on the sign of a zero)"""
+    diff = fast.view(torch.int32) != exact.view(torch.int32)
+    assert bool((exact[diff] == 0).all()) and bool((fast[diff] == 0).all())
+
+
+def test_smooth_division_reciprocal_form_is_ieee(ops, dev):
+    """x / s through the precomputed reciprocal (q = x r, e = x - q s, q + e r) is the IEEE quotient bit for bit (up to
+    the sign of a zero): every fp16 value and LN-sized fp32 values against 2^20 random scales over six decades, plus
+    awkward scales."""
+    g = torch.Generator().manual_seed(11)
+    n = 1 << 20
+    b = torch.exp(torch.rand(n, generator=g) * 13.8 - 6.9).float()             # 1e-3 .. 1e3, log-uniform
+    b[:8] = torch.tensor([1.0, 0.5, 3.0, 1e-5, 1.0000001, 0.99999994, 1.5, 65504.0])
+    h = torch.arange(0, 1 << 16, dtype=torch.int32).to(torch.int16).view(torch.float16).float()
+    h = h[torch.isfinite(h)]
+    a16 = h[torch.randint(0, h.numel(), (n,), generator=g)]
+    a32 = (torch.randn(n, generator=g) * 3.0).float()
+    for a in (a16, a32):
+        for rep in range(4):
+            bb = b[torch.randperm(n, generator=g)]
+            _same_quotients(*ops.smooth_div_check(a.to(dev), bb.to(dev)))
+    # every fp16 value against a handful of scales
+    for sv in (0.37, 1.0 / 3.0, 2.718281, 123.456, 0.001953125):
+        _same_quotients(*ops.smooth_div_check(h.to(dev), torch.full_like(h, sv).to(dev)))
+
+
+def test_smooth_rcp_rejects_channels_outside_the_precondition(ops, dev):
+    good = (torch.rand(1152, generator=torch.Generator().manual_seed(1)) + 0.5).float().to(dev)
+    r = ops.smooth_rcp(good)
+    assert r is not None and torch.equal(r.cpu(), (1.0 / good.cpu().double()).float())
+    assert ops.smooth_rcp(good) is r                                   # cached by tensor identity + version
+    good.mul_(2.0)                                                     # in-place change -> recomputed
+    r2 = ops.smooth_rcp(good)
+    assert r2 is not r and torch.equal(r2.cpu(), (1.0 / good.cpu().double()).float())
+    for badv in (torch.tensor(0x3fffffff, dtype=torch.int32).view(torch.float32).item(), 0.0, -1.0, float("inf"), 1e-39):
+        bad = (torch.rand(1152) + 0.5).float()
+        bad[77] = badv
+        assert ops.smooth_rcp(bad.to(dev)) is None
+
+
+@pytest.mark.parametrize("n_tok", [257, 2048])
+def test_smoothed_quantizers_fast_division_is_bit_identical(ops, dev, n_tok):
+    """The reciprocal-division kernels (half-wave rows, resident smoothing vectors, one workgroup column per output)
+    against the IEEE-division kernels on the same inputs: every output bit-identical, odd row counts included."""
+    C = 1152
+    g = torch.Generator().manual_seed(n_tok)
+    x = h16(1, n_tok, C, scale=2.5, seed=n_tok).to(dev)
+    x[0, 3] = 0                                     # constant row -> eps-fill flag in both
+    sm = [torch.exp(torch.randn(C, generator=g) * 0.7).float().to(dev) for _ in range(3)]
+
+    def same(a, b):
+        for f in ("xq", "sx", "zx", "R"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), f
+
+    st_a, st_b = ops.new_status(dev), ops.new_status(dev)
+    same(ops.rowquant(x, s=sm[0], status=st_a), ops.rowquant(x, s=sm[0], status=st_b, fast_div=False))
+    assert int(st_a.item()) == int(st_b.item())
+    for nb in (8, 6):
+        same(ops.rowquant(x, s=sm[1], n_bits=nb), ops.rowquant(x, s=sm[1], n_bits=nb, fast_div=False))
+    shift = h16(1, C, scale=0.3, seed=5).float().to(dev)
+    scale = h16(1, C, scale=0.3, seed=6).float().to(dev)
+    for smooth in (sm, sm[:1], sm[:2]):
+        # behind LayerNorm the two kernels sum the row in different orders (half-wave vs whole-wave rows): mean / rstd
+        # may differ in the last ulp, so here: the modulated activation within one fp16 ulp, codes within one step on
+        # < 0.5 % of the elements, identical grids up to 1e-6 (test_ln_modulate_rowquant holds both to the oracle)
+        a, xa = ops.ln_modulate_rowquant(x, shift, scale, 1e-6, smooth=smooth, want_xm=True)
+        b, xb = ops.ln_modulate_rowquant(x, shift, scale, 1e-6, smooth=smooth, want_xm=True, fast_div=False)
+        assert float((xa.float() - xb.float()).abs().max()) <= 2.0 ** -8 and float((xa != xb).float().mean()) < 5e-3
+        for qa, qb in zip(a, b):
+            d = (qa.xq.int() - qb.xq.int()).abs()
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 5e-3
+            assert torch.allclose(qa.sx, qb.sx, rtol=1e-6) and int((qa.zx - qb.zx).abs().max()) <= 1
+    # C = 4608 (fc2 input), plain and behind GELU: one row per wave, quotient kept between the two passes
+    x4 = h16(1, n_tok, 4608, scale=2.0, seed=9).to(dev)
+    s4 = torch.exp(torch.randn(4608, generator=g) * 0.7).float().to(dev)
+    same(ops.rowquant(x4, s=s4), ops.rowquant(x4, s=s4, fast_div=False))
+    same(ops.gelu_rowquant(x4, s=s4), ops.gelu_rowquant(x4, s=s4, fast_div=False))
 
 
 # ----------------------------------------------------------------------------- attention
@@ -464,6 +549,49 @@ def test_gemm_i8_batched_equals_separate_launches(ops, dev):
     assert got.shape == (nb, M, N)
     for b in range(nb):
         assert torch.equal(got[b], outs[b])
+
+
+@pytest.mark.parametrize("w_bits", [8, 4])
+@pytest.mark.parametrize("M,G", [(600, 3), (1024, 2), (77, 3)])
+def test_gemm_i8_grouped_equals_separate_launches(ops, dev, w_bits, M, G):
+    """vq_gemm_i8_grouped: the q / k / v Linears of a plan with one smoothing vector per Linear (three quantized copies
+    of the input, three weights) in one grid - bit-identical to one vq_gemm_i8 launch per Linear into the same
+    column block, ragged token tiles included."""
+    N, K = 1152, 1152
+    x = h16(1, M, K, scale=1.5, seed=M).to(dev)
+    g = torch.Generator().manual_seed(5)
+    acts, pws, biases = [], [], []
+    for j in range(G):
+        sm = torch.exp(torch.randn(K, generator=g) * 0.5).float().to(dev)
+        acts.append(ops.rowquant(x, s=sm))
+        W = h16(N, K, scale=0.04, seed=30 + j).to(dev)
+        d, z = ops.weight_minmax(W, w_bits, s=sm)
+        pws.append(ops.pack_weight(W, d, z, w_bits, s=sm))
+        biases.append(h16(N, scale=0.1, seed=40 + j).float().to(dev) if j != 1 else None)
+    ref = torch.zeros((M, 3 * N), dtype=torch.float16, device=dev)
+    for j in range(G):
+        ops.gemm_i8(acts[j], pws[j], bias=biases[j], out=ref[:, j * N:(j + 1) * N])
+    got = torch.zeros((M, 3 * N), dtype=torch.float16, device=dev)
+    ops.gemm_i8_grouped(acts, pws, biases, out=got)
+    assert torch.equal(got, ref)
+
+
+def test_rowquant_multi_equals_separate_launches(ops, dev):
+    C = 1152
+    g = torch.Generator().manual_seed(8)
+    sms = [torch.exp(torch.randn(C, generator=g) * 0.6).float().to(dev) for _ in range(3)]
+    for n_tok in (513, 64):
+        x = h16(1, n_tok, C, scale=2.0, seed=n_tok).to(dev)
+        got = ops.rowquant_multi(x, sms)
+        for qa, sm in zip(got, sms):
+            ref = ops.rowquant(x, s=sm, fast_div=False)
+            for f in ("xq", "sx", "zx", "R"):
+                assert torch.equal(getattr(qa, f), getattr(ref, f)), f
+    # a shape outside the one-launch kernel goes through one vq_rowquant per vector
+    x = h16(1, 16, 96, scale=2.0, seed=1).to(dev)
+    sm96 = [s[:96].contiguous() for s in sms]
+    for qa, sm in zip(ops.rowquant_multi(x, sm96), sm96):
+        assert torch.equal(qa.xq, ops.rowquant(x, s=sm).xq)
 
 
 @pytest.mark.parametrize("w_bits", [8, 4])

@@ -21,15 +21,19 @@ SIGNATURES = {
     "vq_version": (_i, []),
     "vq_strerror": (C.c_char_p, [_i]),
     "vq_last_hip_error": (_i, []),
-    "vq_gelu_rowquant": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "vq_rowquant": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+    "vq_gelu_rowquant": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vq_rowquant": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                          _i, _i, _i, _i, _i, _vp, _vp]),
-    "vq_ln_modulate_rowquant": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+    "vq_ln_modulate_rowquant": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _i, _i, _vp, _vp]),
+    "vq_smooth_reciprocal": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "vq_rowquant_smooth_multi": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vq_smooth_div_check": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
     "vq_fakequant_act": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "vq_pack_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vq_weight_minmax": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vq_gemm_i8_batched": (_i, [_vp] * 10 + [_i] * 6 + [_vp]),
+    "vq_gemm_i8_grouped": (_i, [_i] + [_vp] * 10 + [_i] * 6 + [_vp]),
     "vq_gemm_i8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp,
                         _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "vq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _vp, _f, _vp]),

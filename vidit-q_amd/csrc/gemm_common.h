@@ -42,6 +42,21 @@ struct GemmArgs {
     long bs_w, bs_ch, bs_out;
     int grid_limit;   // > 0: at most this many workgroups (a multiple of 8); they walk the tiles persistently
     int total_tiles;  // set by the launcher for the persistent walk
+    // grouped launch (vq_gemm_i8_grouped): ngroups > 1 independent problems of one shape in ONE grid, group-major
+    // (q / k / v Linears whose inputs were quantized against three smoothing vectors).  Group 0 is the fields above.
+    int ngroups;
+    struct Group {
+        const int8_t* xq;
+        const float* sx;
+        const int32_t* zx;
+        const int32_t* R;
+        const uint8_t* wq;
+        const float* sw;
+        const int32_t* zw;
+        const int32_t* cs;
+        const float* bias;
+        half_t* out;
+    } grp[2];         // groups 1 and 2
 };
 
 // Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (bid % 8), each with its own 4 MiB

@@ -75,3 +75,30 @@ extern "C" int vq_gemm_i8_batched(const int8_t* xq, const float* sx, const int32
     a.bs_out = (long)M * N;
     return launch_gemm_wide<256, 288, 4, 2, true>(a, (hipStream_t)stream);
 }
+
+// ngroups (2 or 3) independent Linears of one shape in one grid: out_g [M, N] = dequant(xq_g . wq_g^T) + bias_g, written
+// to out + g * N with row pitch ldo (the q | k | v column blocks of one [M, 3N] buffer).  The plans that smooth every
+// Linear against its own weight quantize the shared input three times (quant_layer.py:136-160), so q / k / v cannot be
+// one N = 3C GEMM; as three launches each is a single round of 256 tiles whose prologue and store drain nothing
+// overlaps.  Default kernel, no fused epilogue.
+extern "C" int vq_gemm_i8_grouped(int ngroups, const int8_t* const* xq, const float* const* sx, const int32_t* const* zx,
+                                  const int32_t* const* R, const void* const* wq, const float* const* sw,
+                                  const int32_t* const* zw, const int32_t* const* cs, const float* const* bias, void* out,
+                                  int ldo, int M, int N, int K, int Kp, int w_bits, void* stream) {
+    if (ngroups < 1 || ngroups > 3 || !xq || !sx || !zx || !R || !wq || !sw || !zw || !cs || !out) return VQ_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0) return VQ_EINVAL;
+    if (Kp % 128 != 0 || Kp < K || N % 4 != 0 || ldo % 4 != 0 || ldo < ngroups * N) return VQ_ESHAPE;
+    if (w_bits < 2 || w_bits > 8) return VQ_EUNSUP;
+    if (K > 16384) return VQ_ESHAPE;
+    for (int g = 0; g < ngroups; ++g)
+        if (!xq[g] || !sx[g] || !zx[g] || !R[g] || !wq[g] || !sw[g] || !zw[g] || !cs[g]) return VQ_EINVAL;
+    GemmArgs a{xq[0], sx[0], zx[0], R[0], (const uint8_t*)wq[0], sw[0], zw[0], cs[0], bias ? bias[0] : nullptr,
+               (half_t*)out, nullptr, nullptr, ldo, 1, M, N, K, Kp, VQ_EPI_NONE, 0};
+    a.ngroups = ngroups;
+    for (int g = 1; g < ngroups; ++g)
+        a.grp[g - 1] = GemmArgs::Group{xq[g], sx[g], zx[g], R[g], (const uint8_t*)wq[g], sw[g], zw[g], cs[g],
+                                       bias ? bias[g] : nullptr, (half_t*)out + (size_t)g * N};
+    hipStream_t st = (hipStream_t)stream;
+    if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, true, true>(a, st);
+    return launch_gemm_wide<256, 288, 4, 2, true>(a, st);
+}

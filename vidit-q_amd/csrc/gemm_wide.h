@@ -59,6 +59,22 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
             a.cs += (size_t)bt * a.bs_ch;
             if (a.bias) a.bias += (size_t)bt * a.bs_ch;
             a.out += (size_t)bt * a.bs_out;
+        } else if (a.ngroups > 1) {                    // group-major grid; uniform selects, no indexed copy of the args
+            const int g = vb / (MT_ * NT_);
+            vb -= g * (MT_ * NT_);
+            if (g > 0) {
+                const bool g1 = g == 1;
+                a.xq = g1 ? a.grp[0].xq : a.grp[1].xq;
+                a.sx = g1 ? a.grp[0].sx : a.grp[1].sx;
+                a.zx = g1 ? a.grp[0].zx : a.grp[1].zx;
+                a.R = g1 ? a.grp[0].R : a.grp[1].R;
+                a.wq = g1 ? a.grp[0].wq : a.grp[1].wq;
+                a.sw = g1 ? a.grp[0].sw : a.grp[1].sw;
+                a.zw = g1 ? a.grp[0].zw : a.grp[1].zw;
+                a.cs = g1 ? a.grp[0].cs : a.grp[1].cs;
+                a.bias = g1 ? a.grp[0].bias : a.grp[1].bias;
+                a.out = g1 ? a.grp[0].out : a.grp[1].out;
+            }
         }
         xcd_tile(vb, MT_, NT_, mt_, nt_);
     }
@@ -236,7 +252,7 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
-    const int tiles = MT * NTl * (a.nbatch > 1 ? a.nbatch : 1);
+    const int tiles = MT * NTl * (a.nbatch > 1 ? a.nbatch : a.ngroups > 1 ? a.ngroups : 1);
     if (a.grid_limit > 0 && tiles > a.grid_limit) {       // persistent walk on a.grid_limit workgroups
         auto kp = gemm_i8_wide_persist_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4>;
         static hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp),

@@ -16,12 +16,13 @@
 #define RQ_THREADS (RQ_WAVES * 64)
 
 // register-resident hot variants (rowquant_fast.hip); return false when the shape is not covered
-bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, const float* s, int8_t* xq, float* sx,
-                      int32_t* zx, int32_t* R, float* zpf, int n_tok, int C, int Kp, int n_bits, int32_t* status,
-                      hipStream_t st);
+bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, const float* s, const float* s_rcp,
+                      int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf, int n_tok, int C, int Kp, int n_bits,
+                      int32_t* status, hipStream_t st);
 bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float eps, int n_out,
-                 const float* const* s, int8_t* const* xq, float* const* sx, int32_t* const* zx, int32_t* const* R,
-                 half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
+                 const float* const* s, const float* const* s_rcp, int8_t* const* xq, float* const* sx,
+                 int32_t* const* zx, int32_t* const* R, half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status,
+                 hipStream_t st);
 
 __device__ __forceinline__ void store_codes8(int8_t* dst, const int q[8]) {
     uint32_t lo = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) |
@@ -334,11 +335,41 @@ __global__ void adaln_table_kernel(const half_t* __restrict__ table, const half_
     }
 }
 
+// r[c] = RN(1 / s[c]) for the reciprocal form of the smooth-quant division (rq_div_rcp in rowquant_fast.hip), and a count
+// of the channels that break its precondition: s not a positive normal number, significand of s all ones, or the
+// reciprocal not normal.  The host passes the reciprocal to the quantizers only when the count is zero.
+__global__ void smooth_reciprocal_kernel(const float* __restrict__ s, float* __restrict__ r, int n, int32_t* n_bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = s[i];
+    const float q = __fdiv_rn(1.0f, v);
+    r[i] = q;
+    const uint32_t b = __builtin_bit_cast(uint32_t, v), e = (b >> 23) & 0xffu;
+    const uint32_t qe = (__builtin_bit_cast(uint32_t, q) >> 23) & 0xffu;
+    const bool bad = (b >> 31) || e == 0 || e == 0xff || (b & 0x7fffffu) == 0x7fffffu || qe == 0 || qe == 0xff;
+    if (bad) atomicAdd(n_bad, 1);
+}
+
+// quotients of a[i] / b[i] through both forms (test hook for the reciprocal division: tests/test_kernels_gpu.py)
+__device__ __forceinline__ float rq_div_rcp_chk(float a, float b, float rb) {
+    const float q = a * rb;
+    const float e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, rb, q);
+}
+__global__ void smooth_div_check_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ fast,
+                                        float* __restrict__ exact, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float rb = __fdiv_rn(1.0f, b[i]);
+        fast[i] = rq_div_rcp_chk(a[i], b[i], rb);
+        exact[i] = __fdiv_rn(a[i], b[i]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, const float* s, int8_t* xq,
-                           float* sx, int32_t* zx, int32_t* R, float* zpf, const float* delta_in,
+extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, const float* s,
+                           const float* s_rcp, int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf, const float* delta_in,
                            const float* zp_in, int n_param, int B, int n_tok, int C, int Kp, int n_bits,
                            int32_t* status, void* stream) {
     if (!x || !xq || !sx || !zx || !R) return VQ_EINVAL;
@@ -348,7 +379,7 @@ extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int a
     if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
     if (add_rows && (add_div <= 0 || n_add <= 0 || (n_tok + add_div - 1) / add_div > n_add)) return VQ_EINVAL;
     if (B == 1 && !delta_in &&
-        vq_rowquant_fast((const half_t*)x, (const half_t*)add_rows, add_div > 0 ? add_div : 1, s, xq, sx, zx, R, zpf,
+        vq_rowquant_fast((const half_t*)x, (const half_t*)add_rows, add_div > 0 ? add_div : 1, s, s_rcp, xq, sx, zx, R, zpf,
                          n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
         return vq_check_launch();
     dim3 grid((n_tok + RQ_WAVES - 1) / RQ_WAVES);
@@ -358,23 +389,24 @@ extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int a
     return vq_check_launch();
 }
 
-bool vq_gelu_rowquant_fast(const half_t* x, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, int n_tok,
-                           int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
+bool vq_gelu_rowquant_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
+                           int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
 
-extern "C" int vq_gelu_rowquant(const void* x, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, int B,
-                                int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream) {
+extern "C" int vq_gelu_rowquant(const void* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
+                                int32_t* R, int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream) {
     if (!x || !xq || !sx || !zx || !R) return VQ_EINVAL;
     if (B <= 0 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
     if (C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
     if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
     if (B != 1) return VQ_EUNSUP;   // batch-shared token scales: use the GEMM's GELU epilogue + vq_rowquant
-    if (!vq_gelu_rowquant_fast((const half_t*)x, s, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
+    if (!vq_gelu_rowquant_fast((const half_t*)x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
         return VQ_ESHAPE;
     return vq_check_launch();
 }
 
 extern "C" int vq_ln_modulate_rowquant(const void* x, const float* shift, const float* scale, float ln_eps, int n_out,
-                                       const float* const* s, int8_t* const* xq, float* const* sx,
+                                       const float* const* s, const float* const* s_rcp, int8_t* const* xq,
+                                       float* const* sx,
                                        int32_t* const* zx, int32_t* const* R, void* xm_out, int B, int n_tok, int C,
                                        int Kp, int n_bits, int32_t* status, void* stream) {
     if (!x || !shift || !scale || !xq || !sx || !zx || !R) return VQ_EINVAL;
@@ -383,7 +415,7 @@ extern "C" int vq_ln_modulate_rowquant(const void* x, const float* shift, const 
     if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
     for (int j = 0; j < n_out; ++j)
         if (!xq[j] || !sx[j] || !zx[j] || !R[j]) return VQ_EINVAL;
-    if (B == 1 && vq_lnq_fast((const half_t*)x, shift, scale, ln_eps, n_out, s, xq, sx, zx, R, (half_t*)xm_out, n_tok,
+    if (B == 1 && vq_lnq_fast((const half_t*)x, shift, scale, ln_eps, n_out, s, s_rcp, xq, sx, zx, R, (half_t*)xm_out, n_tok,
                               C, Kp, n_bits, status, (hipStream_t)stream))
         return vq_check_launch();
     LnqOut o;
@@ -452,5 +484,36 @@ extern "C" int vq_adaln_table(const void* table, const void* t0, float* mod, int
     int n = B * J * C;
     hipLaunchKernelGGL(adaln_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)table, (const half_t*)t0, mod, B, J, C);
+    return vq_check_launch();
+}
+
+extern "C" int vq_smooth_reciprocal(const float* s, float* r, int n, int32_t* n_bad, void* stream) {
+    if (!s || !r || !n_bad || n <= 0) return VQ_EINVAL;
+    hipLaunchKernelGGL(smooth_reciprocal_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, s, r, n, n_bad);
+    return vq_check_launch();
+}
+
+extern "C" int vq_smooth_div_check(const float* a, const float* b, float* fast, float* exact, long n, void* stream) {
+    if (!a || !b || !fast || !exact || n <= 0) return VQ_EINVAL;
+    hipLaunchKernelGGL(smooth_div_check_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, a, b, fast, exact, n);
+    return vq_check_launch();
+}
+
+bool vq_rowquant_smooth_multi_fast(const half_t* x, int n_out, const float* const* s, const float* const* s_rcp,
+                                   int8_t* const* xq, float* const* sx, int32_t* const* zx, int32_t* const* R, int n_tok,
+                                   int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
+
+extern "C" int vq_rowquant_smooth_multi(const void* x, int n_out, const float* const* s, const float* const* s_rcp,
+                                        int8_t* const* xq, float* const* sx, int32_t* const* zx, int32_t* const* R,
+                                        int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream) {
+    if (!x || !s || !s_rcp || !xq || !sx || !zx || !R) return VQ_EINVAL;
+    if (n_out < 1 || n_out > 3 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
+    if (C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
+    if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
+    for (int j = 0; j < n_out; ++j)
+        if (!s[j] || !s_rcp[j] || !xq[j] || !sx[j] || !zx[j] || !R[j]) return VQ_EINVAL;
+    if (!vq_rowquant_smooth_multi_fast((const half_t*)x, n_out, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status,
+                                       (hipStream_t)stream))
+        return VQ_EUNSUP;
     return vq_check_launch();
 }

@@ -53,14 +53,25 @@ __device__ __forceinline__ uint32_t rq_quant8(const float v[8], float inv, float
     return rq_quant8_t<false>(v, inv, delta, zp, qmax, flip, packed);
 }
 
+// x / s with the reciprocal r = RN(1 / s) precomputed per channel (vq_smooth_reciprocal): q = x r, e = x - q s (exact
+// through the fma), q' = q + e r is the correctly rounded quotient (Markstein's theorem) provided s is a normal number
+// whose significand is not all ones and nothing under/overflows on the way.  vq_smooth_reciprocal counts the channels
+// outside the precondition and the host then passes no reciprocal (IEEE division below, ~4x the instructions).
+// The one visible difference: -0 / s comes out as +0 (e = +0 absorbs the sign); no output of a quantizer depends on it.
+__device__ __forceinline__ float rq_div_rcp(float a, float b, float rb) {
+    const float q = a * rb;
+    const float e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, rb, q);
+}
+
 // ---------------------------------------------------------------------------
 // plain per-token quantizer, B == 1
 // ---------------------------------------------------------------------------
 template <int MAXCH, bool HAS_S, bool HAS_ADD, bool GELU = false>
 __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
     const half_t* __restrict__ x, const half_t* __restrict__ add_rows, int add_div, const float* __restrict__ s,
-    int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R,
-    float* __restrict__ zpf, int n_tok, int C, int Kp, int n_bits, int32_t* status) {
+    const float* __restrict__ s_rcp, int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx,
+    int32_t* __restrict__ R, float* __restrict__ zpf, int n_tok, int C, int Kp, int n_bits, int32_t* status) {
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * RQF_WAVES + (threadIdx.x >> 6);
     if (tok >= n_tok) return;
@@ -83,6 +94,7 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
         }
     }
     float vmin, vmax;
+    float w[(HAS_S || HAS_ADD) ? MAXCH : 1][8];     // the quantizer's input when it is not the row itself
     if constexpr (!HAS_S && !HAS_ADD) {
         half8 mn, mx;
 #pragma unroll
@@ -111,13 +123,21 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
         for (int i = 0; i < MAXCH; ++i) {
             const int c0 = lane * 8 + i * 512;
             if (c0 < C) {
-                if constexpr (HAS_ADD) {  // x + tpe in fp32, kept as fp32 below: re-added in pass 2
+                float sv[8], rv[8];
+                if constexpr (HAS_S) {
+                    *reinterpret_cast<float4v*>(sv) = *reinterpret_cast<const float4v*>(s + c0);
+                    *reinterpret_cast<float4v*>(sv + 4) = *reinterpret_cast<const float4v*>(s + c0 + 4);
+                    if (s_rcp) {   // kernel-uniform
+                        *reinterpret_cast<float4v*>(rv) = *reinterpret_cast<const float4v*>(s_rcp + c0);
+                        *reinterpret_cast<float4v*>(rv + 4) = *reinterpret_cast<const float4v*>(s_rcp + c0 + 4);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = (float)h[i][e];
                     if constexpr (HAS_ADD) v += (float)addp[c0 + e];
-                    if constexpr (HAS_S) v = __fdiv_rn(v, s[c0 + e]);
+                    if constexpr (HAS_S) v = s_rcp ? rq_div_rcp(v, sv[e], rv[e]) : __fdiv_rn(v, sv[e]);
+                    w[i][e] = v;
                     vmin = fminf(vmin, v);
                     vmax = fmaxf(vmax, v);
                 }
@@ -135,18 +155,13 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
 
     int8_t* qrow = xq + (size_t)tok * Kp;
     uint32_t csum = 0;
-    const half_t* addp = HAS_ADD ? add_rows + (size_t)(tok / add_div) * C : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         const int c0 = lane * 8 + i * 512;
         if (c0 < C) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[e] = (float)h[i][e];
-                if constexpr (HAS_ADD) v[e] += (float)addp[c0 + e];
-                if constexpr (HAS_S) v[e] = __fdiv_rn(v[e], s[c0 + e]);
-            }
+            for (int e = 0; e < 8; ++e) v[e] = (HAS_S || HAS_ADD) ? w[i][e] : (float)h[i][e];
             uint2 p;
             csum += rq_quant8(v, inv, delta, zp, qmax, flip, p);
             *reinterpret_cast<uint2*>(qrow + c0) = p;
@@ -264,6 +279,7 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_half_kernel(const half_t
 // ---------------------------------------------------------------------------
 struct LnqFastOut {
     const float* s[3];
+    const float* r[3];     // RN(1 / s) per channel (smooth_rowquant_half_kernel only)
     int8_t* xq[3];
     float* sx[3];
     int32_t* zx[3];
@@ -478,16 +494,171 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// smoothed per-token quantizers at C = 128 * NIT <= 1536, optionally behind LayerNorm + AdaLN modulate, for the plans
+// that balance every Linear against its own weight (W4A8: q / k / v carry three smoothing vectors).
+// What the one-row-per-wave kernels above paid for smoothing was two IEEE divisions per element and output (min/max
+// pass and quantize pass, ~12 VALU instructions each) on top of ~7 for the quantizer itself.  Here
+//   - a half-wave owns a row as in rowquant_half_kernel, and a wave walks RPW row pairs with the smoothing vector, its
+//     reciprocal and (LN) the modulation vectors of ITS output resident in registers;
+//   - x / s is rq_div_rcp (3 instructions, bit-identical to the IEEE quotient) and computed once per element;
+//   - blockIdx.y is the output: the q / k / v copies of one row are produced by three workgroups that each re-read the
+//     row (L2 / MALL hits: the activation is 38 MB) and redo the cheap LN, instead of one wave carrying 3 x 72 extra
+//     registers.  Output 0 also writes the modulated activation when asked for.
+// ---------------------------------------------------------------------------
+template <int NIT, bool LN, int RPW>
+__global__ __launch_bounds__(RQF_THREADS) void smooth_rowquant_half_kernel(
+    const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
+    LnqFastOut o, half_t* __restrict__ xm_out, int n_tok, int n_bits, int32_t* status) {
+    constexpr int C = 128 * NIT;
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const bool hi = lane >= 32;
+    const int j = blockIdx.y;
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int cx = (n_bits == 8) ? 128 : 0;
+    const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
+    const float invC = 1.0f / (float)C;
+    const float* __restrict__ sp = o.s[j];
+    const float* __restrict__ rp = o.r[j];
+    int8_t* __restrict__ xq = o.xq[j];
+    float4v s4[NIT], r4[NIT], sc4[LN ? NIT : 1], sh4[LN ? NIT : 1];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        s4[i] = *reinterpret_cast<const float4v*>(sp + i * 128 + hl * 4);
+        r4[i] = *reinterpret_cast<const float4v*>(rp + i * 128 + hl * 4);
+        if constexpr (LN) {
+            sc4[i] = *reinterpret_cast<const float4v*>(scale + i * 128 + hl * 4);
+            sh4[i] = *reinterpret_cast<const float4v*>(shift + i * 128 + hl * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc4[i][e] = 1.0f + sc4[i][e];
+        }
+    }
+    const int pair0 = (blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)) * RPW;
+    half4 hn[NIT];
+    {
+        int t = pair0 * 2 + (hi ? 1 : 0);
+        t = t < n_tok ? t : n_tok - 1;
+        const half_t* row = x + (size_t)t * C + hl * 4;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) hn[i] = *reinterpret_cast<const half4*>(row + i * 128);
+    }
+    for (int it = 0; it < RPW; ++it) {
+        if ((pair0 + it) * 2 >= n_tok) break;              // wave-uniform
+        int tok = (pair0 + it) * 2 + (hi ? 1 : 0);
+        const bool live = tok < n_tok;
+        if (!live) tok = n_tok - 1;                        // odd tail: the upper half re-does the last row, writes nothing
+        float w[NIT][4];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[i][e] = (float)hn[i][e];
+        if (it + 1 < RPW) {                                // next pair's rows fly under this pair's arithmetic
+            int t = (pair0 + it + 1) * 2 + (hi ? 1 : 0);
+            t = t < n_tok ? t : n_tok - 1;
+            const half_t* row = x + (size_t)t * C + hl * 4;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) hn[i] = *reinterpret_cast<const half4*>(row + i * 128);
+        }
+        if constexpr (LN) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += w[i][e];
+            RQH_REDUCE2(float, vq_addf, sum)
+            const float mu = sum * invC;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = w[i][e] - mu;
+                    sq += d * d;
+                }
+            RQH_REDUCE2(float, vq_addf, sq)
+            const float rstd = __fdiv_rn(1.0f, __fsqrt_rn(sq * invC + ln_eps));
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                half4 hm;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = (w[i][e] - mu) * rstd;
+                    const float u = y * sc4[i][e] + sh4[i][e];
+                    hm[e] = (half_t)u;
+                    w[i][e] = u;
+                }
+                if (xm_out && j == 0 && live) *reinterpret_cast<half4*>(xm_out + (size_t)tok * C + hl * 4 + i * 128) = hm;
+            }
+        }
+        float vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w[i][e] = rq_div_rcp(w[i][e], s4[i][e], r4[i][e]);
+                vmin = fminf(vmin, w[i][e]);
+                vmax = fmaxf(vmax, w[i][e]);
+            }
+        RQH_REDUCE2(float, fminf, vmin)
+        RQH_REDUCE2(float, fmaxf, vmax)
+        float delta, zp;
+        bool small;
+        vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+        if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
+        const float inv = __fdiv_rn(1.0f, delta);
+        const int izx = (int)zp - cx;
+        int8_t* qrow = xq + (size_t)tok * C + hl * 4;
+        uint32_t csum = 0;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float q = rq_round_div(w[i][e], inv, delta) + zp;
+                if (qmax != 255.0f) q = __builtin_amdgcn_fmed3f(q, 0.0f, qmax);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(q, e, pk);
+            }
+            csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
+            if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
+        }
+        int cs = (int)csum;
+        RQH_REDUCE2(int, vq_addi, cs)
+        if (hl == 0 && live) {
+            o.sx[j][tok] = delta;
+            o.zx[j][tok] = izx;
+            o.R[j][tok] = cs - cx * C - C * izx;
+        }
+    }
+}
+
+template <bool LN, int RPW>
+static bool launch_smooth_half(const half_t* x, const float* shift, const float* scale, float eps, const LnqFastOut& o,
+                               int n_out, half_t* xm, int n_tok, int C, int n_bits, int32_t* status, hipStream_t st) {
+    dim3 grid((n_tok + 2 * RQF_WAVES * RPW - 1) / (2 * RQF_WAVES * RPW), n_out);
+#define SMH_GO(N_)                                                                                                  \
+    hipLaunchKernelGGL((smooth_rowquant_half_kernel<N_, LN, RPW>), grid, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
+                       o, xm, n_tok, n_bits, status)
+    switch (C / 128) {
+        case 6: SMH_GO(6); break;
+        case 8: SMH_GO(8); break;
+        case 9: SMH_GO(9); break;
+        case 10: SMH_GO(10); break;
+        default: return false;
+    }
+#undef SMH_GO
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // host dispatch (called from the C ABI entry points in rowquant.hip)
 // ---------------------------------------------------------------------------
 template <int MAXCH>
 static void launch_rq(bool has_s, bool has_add, dim3 grid, hipStream_t st, const half_t* x, const half_t* add_rows,
-                      int add_div, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf,
+                      int add_div, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf,
                       int n_tok, int C, int Kp, int n_bits, int32_t* status) {
     dim3 block(RQF_THREADS);
 #define RQ_GO(S_, A_)                                                                                              \
-    hipLaunchKernelGGL((rowquant_fast_kernel<MAXCH, S_, A_>), grid, block, 0, st, x, add_rows, add_div, s, xq, sx, \
-                       zx, R, zpf, n_tok, C, Kp, n_bits, status)
+    hipLaunchKernelGGL((rowquant_fast_kernel<MAXCH, S_, A_>), grid, block, 0, st, x, add_rows, add_div, s, s_rcp, xq, \
+                       sx, zx, R, zpf, n_tok, C, Kp, n_bits, status)
     if (has_s && has_add) RQ_GO(true, true);
     else if (has_s) RQ_GO(true, false);
     else if (has_add) RQ_GO(false, true);
@@ -495,11 +666,16 @@ static void launch_rq(bool has_s, bool has_add, dim3 grid, hipStream_t st, const
 #undef RQ_GO
 }
 
-bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, const float* s, int8_t* xq, float* sx,
-                      int32_t* zx, int32_t* R, float* zpf, int n_tok, int C, int Kp, int n_bits, int32_t* status,
-                      hipStream_t st) {
+bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, const float* s, const float* s_rcp,
+                      int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf, int n_tok, int C, int Kp, int n_bits,
+                      int32_t* status, hipStream_t st) {
     if (C > 4608 || Kp > 4608) return false;
     const bool hs = s != nullptr, ha = add_rows != nullptr;
+    if (hs && s_rcp && !ha && !zpf && C % 128 == 0 && Kp == C && C >= 768 && C <= 1280 && n_tok >= 2) {
+        LnqFastOut o{};
+        o.s[0] = s, o.r[0] = s_rcp, o.xq[0] = xq, o.sx[0] = sx, o.zx[0] = zx, o.R[0] = R;
+        if (launch_smooth_half<false, 2>(x, nullptr, nullptr, 0.f, o, 1, nullptr, n_tok, C, n_bits, status, st)) return true;
+    }
     if (!hs && !ha && C % 128 == 0 && Kp == C && (C == 1152 || C == 1024 || C == 1280 || C == 768) && n_tok >= 2) {
         dim3 g2((n_tok + 2 * RQF_WAVES - 1) / (2 * RQF_WAVES));
 #define RQH_GO(N_) hipLaunchKernelGGL((rowquant_half_kernel<N_>), g2, dim3(RQF_THREADS), 0, st, x, xq, sx, zx, R, zpf, n_tok, n_bits, status)
@@ -513,9 +689,9 @@ bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, cons
         return true;
     }
     dim3 grid((n_tok + RQF_WAVES - 1) / RQF_WAVES);
-    if (Kp <= 512) launch_rq<1>(hs, ha, grid, st, x, add_rows, add_div, s, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
-    else if (Kp <= 1536) launch_rq<3>(hs, ha, grid, st, x, add_rows, add_div, s, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
-    else launch_rq<9>(hs, ha, grid, st, x, add_rows, add_div, s, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
+    if (Kp <= 512) launch_rq<1>(hs, ha, grid, st, x, add_rows, add_div, s, s_rcp, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
+    else if (Kp <= 1536) launch_rq<3>(hs, ha, grid, st, x, add_rows, add_div, s, s_rcp, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
+    else launch_rq<9>(hs, ha, grid, st, x, add_rows, add_div, s, s_rcp, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
     return true;
 }
 
@@ -536,13 +712,13 @@ static void launch_lnq(int n_out, dim3 grid, hipStream_t st, const half_t* x, co
 }
 
 // GELU(tanh) + (x / s) + per-token quantizer: mlp.act + the activation quantizer of mlp.fc2 in one pass
-bool vq_gelu_rowquant_fast(const half_t* x, const float* s, int8_t* xq, float* sx, int32_t* zx, int32_t* R, int n_tok,
-                           int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+bool vq_gelu_rowquant_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
+                           int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
     if (C > 4608 || Kp > 4608) return false;
     dim3 grid((n_tok + RQF_WAVES - 1) / RQF_WAVES), block(RQF_THREADS);
 #define RQG_GO(M_, S_)                                                                                            \
     hipLaunchKernelGGL((rowquant_fast_kernel<M_, S_, false, true>), grid, block, 0, st, x, (const half_t*)nullptr, 1, s, \
-                       xq, sx, zx, R, (float*)nullptr, n_tok, C, Kp, n_bits, status)
+                       s_rcp, xq, sx, zx, R, (float*)nullptr, n_tok, C, Kp, n_bits, status)
     if (Kp <= 512) { if (s) RQG_GO(1, true); else RQG_GO(1, false); }
     else if (Kp <= 1536) { if (s) RQG_GO(3, true); else RQG_GO(3, false); }
     else { if (s) RQG_GO(9, true); else RQG_GO(9, false); }
@@ -551,9 +727,20 @@ bool vq_gelu_rowquant_fast(const half_t* x, const float* s, int8_t* xq, float* s
 }
 
 bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float eps, int n_out,
-                 const float* const* s, int8_t* const* xq, float* const* sx, int32_t* const* zx, int32_t* const* R,
-                 half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+                 const float* const* s, const float* const* s_rcp, int8_t* const* xq, float* const* sx,
+                 int32_t* const* zx, int32_t* const* R, half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status,
+                 hipStream_t st) {
     if (Kp > 1536) return false;
+    {
+        bool all = s && s_rcp && Kp == C && C % 128 == 0 && C >= 768 && C <= 1280 && n_tok >= 2;
+        for (int j = 0; all && j < n_out; ++j) all = s[j] && s_rcp[j];
+        if (all) {
+            LnqFastOut o{};
+            for (int j = 0; j < n_out; ++j)
+                o.s[j] = s[j], o.r[j] = s_rcp[j], o.xq[j] = xq[j], o.sx[j] = sx[j], o.zx[j] = zx[j], o.R[j] = R[j];
+            if (launch_smooth_half<true, 4>(x, shift, scale, eps, o, n_out, xm, n_tok, C, n_bits, status, st)) return true;
+        }
+    }
     if (n_out == 1 && !(s && s[0]) && !xm && Kp == C && (C == 1152 || C == 1024 || C == 1280 || C == 768) && n_tok >= 2) {
         dim3 g2((n_tok + 2 * RQF_WAVES - 1) / (2 * RQF_WAVES));
 #define LNH_GO(N_)                                                                                              \
@@ -572,6 +759,7 @@ bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float 
     for (int j = 0; j < 3; ++j) {
         const bool on = j < n_out;
         o.s[j] = (on && s) ? s[j] : nullptr;
+        o.r[j] = nullptr;
         o.xq[j] = on ? xq[j] : nullptr;
         o.sx[j] = on ? sx[j] : nullptr;
         o.zx[j] = on ? zx[j] : nullptr;
@@ -581,4 +769,15 @@ bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float 
     if (Kp <= 512) launch_lnq<1>(n_out, grid, st, x, shift, scale, eps, o, xm, n_tok, C, Kp, n_bits, status);
     else launch_lnq<3>(n_out, grid, st, x, shift, scale, eps, o, xm, n_tok, C, Kp, n_bits, status);
     return true;
+}
+
+// n_out smoothed quantizers of one input in one launch (blockIdx.y = output); see smooth_rowquant_half_kernel
+bool vq_rowquant_smooth_multi_fast(const half_t* x, int n_out, const float* const* s, const float* const* s_rcp,
+                                   int8_t* const* xq, float* const* sx, int32_t* const* zx, int32_t* const* R, int n_tok,
+                                   int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+    if (Kp != C || C % 128 != 0 || C < 768 || C > 1280 || n_tok < 2) return false;
+    LnqFastOut o{};
+    for (int j = 0; j < n_out; ++j)
+        o.s[j] = s[j], o.r[j] = s_rcp[j], o.xq[j] = xq[j], o.sx[j] = sx[j], o.zx[j] = zx[j], o.R[j] = R[j];
+    return launch_smooth_half<false, 2>(x, nullptr, nullptr, 0.f, o, n_out, nullptr, n_tok, C, n_bits, status, st);
 }

@@ -83,10 +83,48 @@ def new_status(device) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- quantizers
+# reciprocal of a smooth-quant channel scale, keyed by the tensor (identity + in-place version): computed on first
+# sight (one device round trip for the bad-channel count, so: in the eager warm-up pass, never under graph capture),
+# None when the reciprocal form of x / s is not guaranteed bit-exact for some channel (the kernels then divide)
+_RCP_CACHE: "dict[int, tuple]" = {}
+_RCP_CACHE_MAX = 4096
+
+
+def smooth_rcp(s: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if s is None:
+        return None
+    key = id(s)
+    ent = _RCP_CACHE.get(key)
+    if ent is not None and ent[0]() is s and ent[1] == s._version:
+        return ent[2]
+    if torch.cuda.is_current_stream_capturing():
+        return None                       # an unseen vector under capture: exact division, no host round trip
+    _req(s, torch.float32, "s")
+    r = torch.empty_like(s)
+    bad = torch.zeros(1, dtype=torch.int32, device=s.device)
+    check(_L().vq_smooth_reciprocal(_p(s), _p(r), s.numel(), _p(bad), _stream()), "vq_smooth_reciprocal")
+    out = r if int(bad.item()) == 0 else None
+    if len(_RCP_CACHE) >= _RCP_CACHE_MAX:
+        for k in [k for k, v in _RCP_CACHE.items() if v[0]() is None] or list(_RCP_CACHE)[:_RCP_CACHE_MAX // 2]:
+            _RCP_CACHE.pop(k, None)
+    import weakref
+    _RCP_CACHE[key] = (weakref.ref(s), s._version, out)
+    return out
+
+
+def smooth_div_check(a: torch.Tensor, b: torch.Tensor):
+    """(reciprocal-form quotient, IEEE quotient) of a / b elementwise - test hook."""
+    _req(a, torch.float32, "a")
+    _req(b, torch.float32, "b")
+    fast, exact = torch.empty_like(a), torch.empty_like(a)
+    check(_L().vq_smooth_div_check(_p(a), _p(b), _p(fast), _p(exact), a.numel(), _stream()), "vq_smooth_div_check")
+    return fast, exact
+
+
 def rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
              add_rows: Optional[torch.Tensor] = None, add_div: int = 1,
              status: Optional[torch.Tensor] = None, want_zp: bool = False,
-             delta: Optional[torch.Tensor] = None, zp: Optional[torch.Tensor] = None) -> QAct:
+             delta: Optional[torch.Tensor] = None, zp: Optional[torch.Tensor] = None, fast_div: bool = True) -> QAct:
     """Per-token quantizer of x [B, n_tok, C] fp16 (scales shared over B): dynamic min-max, or on a
     static calibrated grid when ``delta``/``zp`` (1 or n_tok entries) are given."""
     _req(x, torch.float16, "x")
@@ -112,14 +150,37 @@ def rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
         delta = _req(delta.reshape(-1).contiguous(), torch.float32, "delta")
         zp = _req(zp.reshape(-1).contiguous(), torch.float32, "zp")
         n_param = delta.numel()
-    check(_L().vq_rowquant(_p(x), _p(add_rows), n_add, add_div, _p(s), _p(xq), _p(sx), _p(zx), _p(R), _p(zpf),
+    s_rcp = smooth_rcp(s) if fast_div else None
+    check(_L().vq_rowquant(_p(x), _p(add_rows), n_add, add_div, _p(s), _p(s_rcp), _p(xq), _p(sx), _p(zx), _p(R), _p(zpf),
                            _p(delta), _p(zp), n_param, B, n_tok, Cc, Kp, n_bits, _p(status), _stream()),
           "vq_rowquant")
     return QAct(xq, sx, zx, R, Cc, n_bits, zpf)
 
 
+def rowquant_multi(x: torch.Tensor, smooth: Sequence[torch.Tensor], n_bits: int = 8,
+                   status: Optional[torch.Tensor] = None) -> List[QAct]:
+    """One QAct of x [1, n_tok, C] per smoothing vector (the q / k / v quantizers of a plan that balances each Linear
+    against its own weight) in ONE launch when the reciprocal-form kernel covers the shape, else one launch each."""
+    _req(x, torch.float16, "x")
+    B, n_tok, Cc = x.shape
+    rcps = [smooth_rcp(sm) for sm in smooth]
+    Kp = pad128(Cc)
+    G = len(smooth)
+    if B != 1 or G > 3 or any(r is None for r in rcps) or Kp != Cc or Cc % 128 or not (768 <= Cc <= 1280) or n_tok < 2:
+        return [rowquant(x, n_bits=n_bits, s=sm, status=status) for sm in smooth]
+    dev = x.device
+    outs = [QAct(torch.empty((n_tok, Kp), dtype=torch.int8, device=dev), torch.empty(n_tok, dtype=torch.float32, device=dev),
+                 torch.empty(n_tok, dtype=torch.int32, device=dev), torch.empty(n_tok, dtype=torch.int32, device=dev),
+                 Cc, n_bits) for _ in range(G)]
+    keep = [_ptr_array([_p(sm) for sm in smooth]), _ptr_array([_p(r) for r in rcps])] + \
+           [_ptr_array([getattr(o, f).data_ptr() for o in outs]) for f in ("xq", "sx", "zx", "R")]
+    check(_L().vq_rowquant_smooth_multi(_p(x), G, *[C.cast(k, C.c_void_p) for k in keep], n_tok, Cc, Kp, n_bits,
+                                        _p(status), _stream()), "vq_rowquant_smooth_multi")
+    return outs
+
+
 def gelu_rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
-                  status: Optional[torch.Tensor] = None) -> QAct:
+                  status: Optional[torch.Tensor] = None, fast_div: bool = True) -> QAct:
     """GELU(tanh) then the per-token quantizer of x [1, n_tok, C] fp16 (the fc1 -> act -> fc2-quantizer hand-over)."""
     _req(x, torch.float16, "x")
     B, n_tok, Cc = x.shape
@@ -131,14 +192,15 @@ def gelu_rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = 
     R = torch.empty(n_tok, dtype=torch.int32, device=dev)
     if s is not None:
         _req(s, torch.float32, "s")
-    check(_L().vq_gelu_rowquant(_p(x), _p(s), _p(xq), _p(sx), _p(zx), _p(R), B, n_tok, Cc, Kp, n_bits, _p(status),
-                                _stream()), "vq_gelu_rowquant")
+    s_rcp = smooth_rcp(s) if fast_div else None
+    check(_L().vq_gelu_rowquant(_p(x), _p(s), _p(s_rcp), _p(xq), _p(sx), _p(zx), _p(R), B, n_tok, Cc, Kp, n_bits,
+                                _p(status), _stream()), "vq_gelu_rowquant")
     return QAct(xq, sx, zx, R, Cc, n_bits, None)
 
 
 def ln_modulate_rowquant(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-6,
                          smooth: Sequence[Optional[torch.Tensor]] = (None,), n_bits: int = 8,
-                         status: Optional[torch.Tensor] = None, want_xm: bool = False):
+                         status: Optional[torch.Tensor] = None, want_xm: bool = False, fast_div: bool = True):
     """LN(no affine) + (1+scale)*.+shift + per-token quant; one QAct per entry of ``smooth``."""
     _req(x, torch.float16, "x")
     B, n_tok, Cc = x.shape
@@ -165,13 +227,15 @@ def ln_modulate_rowquant(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tens
         if sm is not None:
             _req(sm, torch.float32, "smooth")
     s_arr = mk([_p(sm) for sm in smooth])
+    rcps = [smooth_rcp(sm) if fast_div else None for sm in smooth]     # kept alive until the launch is enqueued
+    r_arr = mk([_p(r) for r in rcps])
     xq_arr = mk([o.xq.data_ptr() for o in outs])
     sx_arr = mk([o.sx.data_ptr() for o in outs])
     zx_arr = mk([o.zx.data_ptr() for o in outs])
     R_arr = mk([o.R.data_ptr() for o in outs])
     xm = torch.empty_like(x) if want_xm else None
     check(_L().vq_ln_modulate_rowquant(_p(x), _p(shift), _p(scale), float(eps), n_out,
-                                       C.cast(s_arr, C.c_void_p), C.cast(xq_arr, C.c_void_p),
+                                       C.cast(s_arr, C.c_void_p), C.cast(r_arr, C.c_void_p), C.cast(xq_arr, C.c_void_p),
                                        C.cast(sx_arr, C.c_void_p), C.cast(zx_arr, C.c_void_p),
                                        C.cast(R_arr, C.c_void_p), _p(xm), B, n_tok, Cc, Kp, n_bits,
                                        _p(status), _stream()), "vq_ln_modulate_rowquant")
@@ -340,6 +404,33 @@ def gemm_i8_batched(a: QAct, w: PackedStack, out: Optional[torch.Tensor] = None)
     check(_L().vq_gemm_i8_batched(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs),
                                   _p(w.bias), _p(out), w.nbatch, M, w.N, a.K, a.Kp, w.n_bits, _stream()),
           "vq_gemm_i8_batched")
+    return out
+
+
+def _ptr_array(vals, n=3):
+    arr = (C.c_void_p * n)(*[C.c_void_p(v) if v is not None else None for v in list(vals) + [None] * (n - len(vals))])
+    return arr
+
+
+def gemm_i8_grouped(acts: Sequence[QAct], ws: Sequence[PackedWeight], biases: Optional[Sequence] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """2 or 3 Linears of one shape in one launch: out[:, g*N:(g+1)*N] = Linear_g(acts[g]) (q | k | v blocks)."""
+    G = len(acts)
+    assert 1 <= G <= 3 and len(ws) == G
+    a0, w0 = acts[0], ws[0]
+    for a, w in zip(acts, ws):
+        if (a.K, a.Kp, a.rows) != (a0.K, a0.Kp, a0.rows) or (w.N, w.K, w.Kp, w.n_bits) != (w0.N, w0.K, w0.Kp, w0.n_bits) \
+                or a.K != w.K or a.Kp != w.Kp:
+            raise VQError("grouped GEMM needs one shape for every group")
+    M, N = a0.rows, w0.N
+    if out is None:
+        out = torch.empty((M, G * N), dtype=torch.float16, device=a0.xq.device)
+    assert out.dtype == torch.float16 and out.stride(-1) == 1 and out.shape[-1] >= G * N
+    bs = [None] * G if biases is None else [None if b is None else _req(b, torch.float32, "bias") for b in biases]
+    keep = [_ptr_array([_p(getattr(a, f)) for a in acts]) for f in ("xq", "sx", "zx", "R")] + \
+           [_ptr_array([_p(getattr(w, f)) for w in ws]) for f in ("wq", "sw", "zw", "cs")] + [_ptr_array([_p(b) for b in bs])]
+    check(_L().vq_gemm_i8_grouped(G, *[C.cast(k, C.c_void_p) for k in keep], _p(out), out.stride(0), M, N, a0.K, a0.Kp,
+                                  w0.n_bits, _stream()), "vq_gemm_i8_grouped")
     return out
 
 

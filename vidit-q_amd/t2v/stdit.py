@@ -435,6 +435,10 @@ class STDiTBlock(nn.Module):
             qkv = torch.empty((M, 3 * C), dtype=torch.float16, device=dev)
             if fused is not None and len(qas) == 1:
                 ops.gemm_i8(qas[0], fused[0], bias=fused[1], out=qkv)
+            elif len({(p.N, p.K, p.Kp, p.n_bits) for p in pws}) == 1 and len({(a.K, a.Kp) for a in qas}) == 1:
+                # three smoothing vectors -> three quantized copies of the input: one grouped launch (q | k | v blocks)
+                ops.gemm_i8_grouped([qas[j if len(qas) > 1 else 0] for j in range(3)], pws,
+                                    [l.bias_f32() for l in (att.q, att.k, att.v)], out=qkv)
             else:
                 for j, l in enumerate((att.q, att.k, att.v)):
                     ops.gemm_i8(qas[j if len(qas) > 1 else 0], pws[j], bias=l.bias_f32(),
@@ -455,6 +459,10 @@ class STDiTBlock(nn.Module):
         tpe2 = None if tpe is None else tpe.reshape(T, C).contiguous()
         if all(s is None for s in svs) and isinstance(a2.q.act_quantizer, DynamicActQuantizer):
             qas = [a2.q.quantize_input(x3, None, add_rows=tpe2, add_div=S)]
+        elif tpe2 is None and B == 1 and all(s is not None for s in svs) and all(
+                isinstance(l.act_quantizer, DynamicActQuantizer) for l in (a2.q, a2.k, a2.v)) and len(
+                {l.act_quantizer.n_bits for l in (a2.q, a2.k, a2.v)}) == 1:
+            qas = ops.rowquant_multi(x3, svs, n_bits=a2.q.act_quantizer.n_bits, status=a2.q.status)   # one launch
         else:
             qas = [l.quantize_input(x3, s, add_rows=tpe2, add_div=S) for l, s in zip((a2.q, a2.k, a2.v), svs)]
         qkv = qkv_proj(a2, qas)
