@@ -40,8 +40,6 @@ struct GemmArgs {
     // of the respective arrays (wq bytes, per-channel arrays, out halves)
     int nbatch;
     long bs_w, bs_ch, bs_out;
-    int grid_limit;   // > 0: at most this many workgroups (a multiple of 8); they walk the tiles persistently
-    int total_tiles;  // set by the launcher for the persistent walk
     // grouped launch (vq_gemm_i8_grouped): ngroups > 1 independent problems of one shape in ONE grid, group-major
     // (q / k / v Linears whose inputs were quantized against three smoothing vectors).  Group 0 is the fields above.
     int ngroups;

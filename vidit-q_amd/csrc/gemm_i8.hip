@@ -42,10 +42,6 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
     GemmArgs a{xq, sx, zx, R, (const uint8_t*)wq, sw, zw, cs, bias, (half_t*)out, (const half_t*)resid, gate,
                ldo, rows_per_gate > 0 ? rows_per_gate : 1, M, N, K, Kp, epilogue, 0};
     hipStream_t st = (hipStream_t)stream;
-    {
-        static const int grid_env = getenv("VQ_GEMM_GRID") ? atoi(getenv("VQ_GEMM_GRID")) : 0;   // experiment switch
-        a.grid_limit = grid_env > 0 ? (grid_env + 7) / 8 * 8 : 0;
-    }
     switch (variant) {
         case VQ_GEMM_DEFAULT:
         case 11:  // full-line double buffer: 128 bytes of k per row and stage, staggered DMA issue

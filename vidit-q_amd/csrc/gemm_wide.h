@@ -15,10 +15,6 @@
 // LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row >> 1) & 7 (W4: 64 B rows, (row >> 2) & 3).
 // ---------------------------------------------------------------------------
 // ABL (profiling only, results wrong): 1 no DMA after the prologue, 2 no MFMA, 4 no barrier, 8 no fragment reads
-// PERSIST: the grid is smaller than the tile count and workgroup b walks tiles b, b + G, b + 2G, ... (G a multiple of 8,
-// so a workgroup stays on the XCD whose L2 holds its operand panels).  A grid of fewer workgroups than CUs leaves
-// whole CUs to the other stream's kernels (cond / uncond run as two streams): the HBM-bound quantizer / attention
-// kernels of one sample then run BESIDE the other sample's GEMM instead of queueing behind its full-chip launch.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>
 __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, const int tid_) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -229,21 +225,6 @@ __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(Gem
     gemm_i8_wide_tile<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4, ABL>(a, blockIdx.x, threadIdx.x);
 }
 
-// PERSISTENT launch: the grid is smaller than the tile count and workgroup b walks tiles b, b + G, b + 2G, ... (G a
-// multiple of 8, so a workgroup stays on the XCD whose L2 holds its operand panels).  A grid of fewer workgroups than
-// CUs leaves whole CUs to the other stream's kernels (cond / uncond run as two streams): the HBM-bound quantizer /
-// attention kernels of one sample then run BESIDE the other sample's GEMM instead of queueing behind its full-chip
-// launch.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
-__global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_persist_kernel(GemmArgs a) {
-    for (int vb0 = blockIdx.x; vb0 < a.total_tiles; vb0 += gridDim.x) {
-        int tx = threadIdx.x;
-        asm volatile("" : "+v"(tx));      // opaque per tile: lane-dependent addresses are recomputed, not carried in VGPRs
-        gemm_i8_wide_tile<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4, 0>(a, vb0, tx);
-        __syncthreads();                  // every wave is done with its slab before the ring refills
-    }
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
 static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -253,19 +234,6 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
     const int tiles = MT * NTl * (a.nbatch > 1 ? a.nbatch : a.ngroups > 1 ? a.ngroups : 1);
-    if (a.grid_limit > 0 && tiles > a.grid_limit) {       // persistent walk on a.grid_limit workgroups
-        auto kp = gemm_i8_wide_persist_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4>;
-        static hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
-        if (ep != hipSuccess) {
-            g_vq_last_hip_error = (int)ep;
-            return VQ_ELAUNCH;
-        }
-        GemmArgs b = a;
-        b.total_tiles = tiles;
-        hipLaunchKernelGGL(kp, dim3(a.grid_limit), dim3(NT), LDS, st, b);
-        return vq_check_launch();
-    }
     auto k = gemm_i8_wide_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
