@@ -50,7 +50,7 @@ cal_copy_f = cal_copy_f[0] if cal_copy_f else float("nan")
 def short(k):
     for a, b in (("gemm_i8_wide_kernel<256, 288, 4, 2, 0", "GEMM epi none (qkv x2, cross-q, kv)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 1", "GEMM fc1 + GELU"),
                  ("gemm_i8_wide_kernel<256, 288, 4, 2, 2", "GEMM + gate*y + resid (proj x2, fc2)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 3", "GEMM + resid (cross proj)"),
-                 ("attn_fwd8_kernel", "spatial attention (flash, 1024 keys)"), ("attn_temporal_quant", "temporal attention + proj quantizer"),
+                 ("attn_fwd32d_kernel", "spatial attention (flash, 1024 keys)"), ("attn_fwd8_kernel", "spatial attention, previous generation"), ("attn_temporal_quant", "temporal attention + proj quantizer"),
                  ("attn_cross_reg", "cross attention (K/V^T in registers)"), ("ln_modulate_rowquant_half", "LN + modulate + quantizer C=1152"),
                  ("rowquant_half", "per-token quantizer C=1152"), ("rowquant_fast_kernelILi9", "per-token quantizer C=4608")):
         if a in k:
