@@ -76,10 +76,6 @@ int main() {
         run<64, 0, true, false>("8 MFMA + 64 v_fma interleaved (same wave)", nw);
         run<0, 32, true, false>("8 MFMA + 32 v_exp interleaved (same wave)", nw);
         run<64, 32, true, false>("8 MFMA + 64 v_fma + 32 v_exp (same wave)", nw);
-        if (nw >= 8) {
-            run<64, 0, true, true>("split: MFMA waves | 64 v_fma waves", nw);
-            run<64, 32, true, true>("split: MFMA waves | fma + exp waves", nw);
-        }
     }
     return 0;
 }
