@@ -6,6 +6,7 @@
 //   20/21 half-CU workgroups                       100+  ablations / cycle stamps of the shipping kernel (variant 11)
 // What each one taught is in DESIGN.md (5).  The shipping kernels live in vidit-q_amd/csrc/gemm_i8.hip.
 #include "../../vidit-q_amd/csrc/gemm_wide.h"
+#include "gemm_half.h"
 
 int g_vq_last_hip_error = 0;
 
@@ -1385,6 +1386,9 @@ extern "C" int vq_lab_gemm_i8(const int8_t* xq, const float* sx, const int32_t* 
         case 11:  // full-line double buffer: 128 bytes of k per row and stage, staggered DMA issue
             if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, true, true>(a, st);
             return launch_gemm_wide<256, 288, 4, 2, true>(a, st);
+        case 22:  // two co-resident 128 x 288 workgroups per CU, 64-byte stages, 3-stage ring (gemm_half.h); int8 weights
+            if (w_bits <= 4) return VQ_EUNSUP;
+            return launch_gemm_pair(a, st);
         case 14: {  // persistent full-line ring with next-tile prefetch where a launch has more tiles than CUs
             const int tiles = ((a.M + 255) / 256) * ((a.N + 287) / 288);
             if (w_bits > 4 && a.nbatch <= 1 && a.Kp >= 256 && tiles > vq_num_cus()) {
