@@ -106,16 +106,31 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
             soff[i] = (uint32_t)gn * (uint32_t)(a.Kp >> 1) + c * 16;
         }
     }
-    const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.xq);
+    // LDS-DMA through buffer loads: SGPR resource (token or weight base), one VGPR byte offset per piece (constant over
+    // k), the k offset in an SGPR - no 64-bit address arithmetic per piece and stage.  Issued through asm with
+    // M0 = LDS destination; every wait on these transfers in this kernel is an explicit s_waitcnt vmcnt.
+    auto mk_rsrc = [&](const void* base) {
+        const unsigned long ba = (unsigned long)base;
+        return int4v{(int)__builtin_amdgcn_readfirstlane((unsigned)ba),
+                     (int)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu), (int)0xffffffffu, 0x00020000};
+    };
+    const int4v rs_x = mk_rsrc(a.xq), rs_w = mk_rsrc(a.wq);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
     auto issue = [&](int stage, int kt) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wave + i * NW;
             if (PIECES % NW == 0 || p < PIECES) {
-                const uint8_t* g = p < XP ? xbase + soff[i] + kt * 128 : a.wq + soff[i] + kt * WROW;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
-                                                 (void __attribute__((address_space(3)))*)(smem + stage * STAGE + p * 1024),
-                                                 16, 0, 0);
+                const unsigned dst = lds0 + stage * STAGE + p * 1024;
+                if (p < XP) {
+                    const int koff = kt * 128;
+                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_x), "s"(koff)
+                                 : "memory", "m0");
+                } else {
+                    const int koff = kt * WROW;
+                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_w), "s"(koff)
+                                 : "memory", "m0");
+                }
             }
         }
     };
