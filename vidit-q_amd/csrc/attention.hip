@@ -419,6 +419,7 @@ struct TempQArgs {
 
 // HC: head count known at compile time (16 = STDiT-XL; 0 = take a.H): the chunk -> (tensor, row, piece) divisions of
 // the staging loops are by H * D / 8 and cost ~45 VALU instructions each with a run-time divisor
+typedef __fp16 h4t_t __attribute__((__vector_size__(4 * sizeof(__fp16))));   // operand type of the LDS transpose read
 template <int D, int HC>
 __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) {
     constexpr int KS = (D + 15) / 16;              // 16-dim k-steps of QK^T = 16-dim row tiles of O^T
@@ -431,18 +432,23 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
     const int TILE = 16 * RS;
     const int RCH = C / 8;                         // 16-byte chunks per tensor row
     const int CROW = C + 16;                       // code row stride in LDS (rows land 4 banks apart)
-    uint8_t* codes = smem + 3 * TILE;
+    uint8_t* codes = smem + TILE;                 // [V tile | codes | row statistics]
     float* ex_min = reinterpret_cast<float*>(codes + 16 * CROW);
     float* ex_max = ex_min + 256;
     int* ex_sum = reinterpret_cast<int*>(ex_max + 256);
     const int npos = a.S * a.B;
 
-    // One workgroup walks positions p, p + G, ...: while position p is computed from LDS, the q | k | v rows of the
-    // next one are in flight into registers (a one-position-per-workgroup version ran load -> compute -> store in
-    // lockstep on every CU: 2.8 TB/s).
-    constexpr int NITMAX = 7;                      // 3 * 16 * 144 chunks / 1024 threads (H = 16, D = 72)
-    const int nchk = 3 * 16 * RCH;
+    // One workgroup walks positions p, p + G, ...: while position p is computed, the rows of the next one are in flight
+    // into registers (a one-position-per-workgroup version ran load -> compute -> store in lockstep on every CU:
+    // 2.8 TB/s).  Only V goes through LDS (its MFMA operand is the transpose of the stored rows); the K and Q
+    // operands of S^T = K Q^T are the stored rows themselves - lane (tq, g4) needs 4 dims of row tq per k-step - and
+    // come straight from global memory in operand form: staging all of q | k | v (111 KB per position) through
+    // ds_write_b128 at ~79 B/clk was 1400 of the ~1600 cycles a position took.
+    constexpr int NITMAX = 3;                      // 16 * 144 V chunks / 1024 threads (H = 16, D = 72)
+    const int nchk = 16 * RCH;
     int4v vals[NITMAX];
+    constexpr int KS2 = (D + 31) / 32;             // 32-dim k-steps of the 16x16x32 form of QK^T
+    half8 kfn[KS2], qfn[KS2];                      // next position's operands (in flight), copied over after use
     // (tx: an opaque per-position copy of the thread id, so that the chunk -> address arithmetic is recomputed per
     //  position instead of being hoisted out of the loop and kept in registers)
     auto load_qkv = [&](int pos, int tx) {
@@ -450,13 +456,30 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
 #pragma unroll
         for (int i = 0; i < NITMAX; ++i) {
             const int c = tx + i * nthr;
-            const int ten = c / (16 * RCH), rem = c - ten * (16 * RCH);
-            const int t = rem / RCH, ch = rem - t * RCH;
+            const int t = c / RCH, ch = c - t * RCH;
             vals[i] = int4v{0, 0, 0, 0};
             if (c < nchk && t < a.T) {
-                const half_t* base = ten == 0 ? a.q : (ten == 1 ? a.k : a.v);
                 const long grow = ((long)b * a.T + t) * a.S + s;
-                vals[i] = *reinterpret_cast<const int4v*>(base + grow * a.ld_in + ch * 8);
+                vals[i] = *reinterpret_cast<const int4v*>(a.v + grow * a.ld_in + ch * 8);
+            }
+        }
+        // 16x16x32 operand form: lane (row tq, k-group g4) holds dims 32 * step + 8 * g4 .. + 7 of row tq - one 16-byte
+        // load, and the four k-groups of a row read 64 contiguous bytes (whole cache lines, like the GEMM's DMA pieces)
+        const int ln = tx & 63, tq_ = ln & 15, g4_ = ln >> 4;
+        const long grow = ((long)b * a.T + (tq_ < a.T ? tq_ : 0)) * a.S + s;
+        const half_t* krow = a.k + grow * a.ld_in + wave * D;
+        const half_t* qrow = a.q + grow * a.ld_in + wave * D;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+            const int d0 = ks * 32 + 8 * g4_;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                kfn[ks][e] = (half_t)0.f;
+                qfn[ks][e] = (half_t)0.f;
+            }
+            if (d0 < D && tq_ < a.T) {
+                kfn[ks] = *reinterpret_cast<const half8*>(krow + d0);
+                qfn[ks] = *reinterpret_cast<const half8*>(qrow + d0);
             }
         }
     };
@@ -464,19 +487,22 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
 #pragma unroll
         for (int i = 0; i < NITMAX; ++i) {
             const int c = tx + i * nthr;
-            const int ten = c / (16 * RCH), rem = c - ten * (16 * RCH);
-            const int t = rem / RCH, ch = rem - t * RCH;
-            if (c < nchk) *reinterpret_cast<int4v*>(smem + ten * TILE + t * RS + ch * 16) = vals[i];
+            const int t = c / RCH, ch = c - t * RCH;
+            if (c < nchk) *reinterpret_cast<int4v*>(smem + t * RS + ch * 16) = vals[i];
         }
     };
-    const uint8_t* qs = smem + wave * D * 2;
-    const uint8_t* ksm = qs + TILE;
-    const uint8_t* vs = qs + 2 * TILE;
+    const uint8_t* vs = smem + wave * D * 2;
 
     int pos = blockIdx.x;
     if (pos >= npos) return;
     load_qkv(pos, tid);
     store_qkv(tid);
+    half8 kfc[KS2], qfc[KS2];
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+        kfc[ks] = kfn[ks];
+        qfc[ks] = qfn[ks];
+    }
     __syncthreads();
     if (pos + (int)gridDim.x < npos) load_qkv(pos + (int)gridDim.x, tid);
     for (; pos < npos; pos += gridDim.x) {
@@ -486,19 +512,10 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
         int tx = tid;
         asm volatile("" : "+v"(tx));
 
-        // ---- S^T[key 4*g4 + r][query tq] = K Q^T, 16 x 16 per head: lane reads 4 dims of key row tq and of query row tq
+        // ---- S^T[key 4*g4 + r][query tq] = K Q^T, 16 x 16 per head: lane holds 8 dims of key row tq and of query row tq
         float4v sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int d0 = ks * 16 + 4 * g4;
-            half4 kf = *reinterpret_cast<const half4*>(ksm + tq * RS + (d0 < D ? d0 : 0) * 2);
-            half4 qf = *reinterpret_cast<const half4*>(qs + tq * RS + (d0 < D ? d0 : 0) * 2);
-            if (d0 >= D) {
-                kf = half4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-                qf = kf;
-            }
-            sc = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf, sc, 0, 0, 0);
-        }
+        for (int ks = 0; ks < KS2; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfc[ks], qfc[ks], sc, 0, 0, 0);
         float mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -525,11 +542,13 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
         float vmin = INFINITY, vmax = -INFINITY;
 #pragma unroll
         for (int dt = 0; dt < KS; ++dt) {
-            const int d = dt * 16 + tq;
-            half4 vf;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                vf[r] = d < D ? *reinterpret_cast<const half_t*>(vs + (4 * g4 + r) * RS + d * 2) : (half_t)0.f;
+            // V^T operand (dim tq, keys 4 g4 .. + 3) by ONE LDS transpose read of the row-major tile: lane i of a 16-lane
+            // group points at [key 4 g4 + i / 4][dims 16 dt + 4 (i % 4) .. + 3] and receives column i of the 4 x 16 block
+            // (four 2-byte reads and their packing before).  Dims >= D of the last tile read the neighbouring head / the
+            // row padding: finite garbage in output rows nobody stores.
+            const h4t_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (__attribute__((address_space(3))) h4t_t*)(vs + (4 * g4 + (tq >> 2)) * RS + (dt * 16 + 4 * (tq & 3)) * 2));
+            const half4 vf = {(half_t)vt[0], (half_t)vt[1], (half_t)vt[2], (half_t)vt[3]};
             oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             // this lane: token tq, dims 16*dt + 4*g4 + r, rounded to fp16 like the stored tensor
 #pragma unroll
@@ -568,8 +587,13 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // row statistics visible; every wave is done with the q | k | v tiles
         if (has_next) {
-            store_qkv(tx);                         // next position's rows (visible after the barrier below) ...
-            if (npos_next + (int)gridDim.x < npos) load_qkv(npos_next + (int)gridDim.x, tx);   // ... and the one after it
+            store_qkv(tx);                         // next position's V rows (visible after the barrier below) ...
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {     // ... its K / Q operands move into the current set ...
+                kfc[ks] = kfn[ks];
+                qfc[ks] = qfn[ks];
+            }
+            if (npos_next + (int)gridDim.x < npos) load_qkv(npos_next + (int)gridDim.x, tx);   // ... and the position after it is requested
         }
         vmin = INFINITY;
         vmax = -INFINITY;
@@ -1532,9 +1556,9 @@ extern "C" int vq_attn_temporal(const void* q, const void* k, const void* v, voi
 template <int D>
 static int launch_temporal_quant(const TempQArgs& a, hipStream_t st) {
     const int C = a.H * D;
-    const int LDS = 3 * 16 * (C * 2 + 16) + 16 * (C + 16) + 3 * 1024;
+    const int LDS = 16 * (C * 2 + 16) + 16 * (C + 16) + 3 * 1024;
     auto k = a.H == 16 ? attn_temporal_quant_kernel<D, 16> : attn_temporal_quant_kernel<D, 0>;
-    constexpr int LDS_MAX = 3 * 16 * (16 * 72 * 2 + 16) + 16 * (16 * 72 + 16) + 3 * 1024;
+    constexpr int LDS_MAX = 16 * (16 * 72 * 2 + 16) + 16 * (16 * 72 + 16) + 3 * 1024;
     static hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_temporal_quant_kernel<D, 0>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
     static hipError_t e = e0 != hipSuccess ? e0 : hipFuncSetAttribute(reinterpret_cast<const void*>(attn_temporal_quant_kernel<D, 16>),
@@ -1543,7 +1567,7 @@ static int launch_temporal_quant(const TempQArgs& a, hipStream_t st) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
     }
-    // persistent: LDS (133 KB at H*D = 1152) admits one workgroup per CU; small problems get one position each
+    // persistent: a 1024-thread workgroup at up to 128 VGPRs owns its CU; small problems get one position each
     const int npos = a.S * a.B;
     static int ncu = [] {
         int dev = 0, v = 0;
@@ -1551,7 +1575,7 @@ static int launch_temporal_quant(const TempQArgs& a, hipStream_t st) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
         return v;
     }();
-    const int per_cu = LDS > 80 * 1024 ? 1 : (LDS > 52 * 1024 ? 2 : 3);
+    const int per_cu = a.H > 8 ? 1 : (LDS > 80 * 1024 ? 1 : (LDS > 52 * 1024 ? 2 : 3));
     const int grid = npos < ncu * per_cu ? npos : ncu * per_cu;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * a.H), LDS, st, a);
     return vq_check_launch();
