@@ -222,13 +222,15 @@ int vq_attn_temporal(const void* q, const void* k, const void* v, void* o,
 /* Temporal attention fused with the per-token 8-bit dynamic quantizer of the Linear that consumes its output
  * (attn_temp.proj: stdit.py:116 -> QuantTemporalAttnLinear.forward, stdit_quant_layer.py:161-166 ->
  * DynamicActQuantizer, dynamic_quantizer.py:16-45) for B == 1 per forward: the fp16 attention output is
- * rounded as vq_attn_temporal would store it but never written; outputs are what vq_rowquant(n_bits = 8, no
- * smoothing) would produce from it (xq [B*T*S, Kp] codes - 128 with zeroed pad columns, sx, zx, R; status as
- * there).  o: nullable, dense [B*T*S, H*D] fp16 copy of the attention output for callers that need both.
+ * rounded as vq_attn_temporal would store it but never written; outputs are what vq_rowquant(n_bits = 8, s, s_rcp)
+ * would produce from it (xq [B*T*S, Kp] codes - 128 with zeroed pad columns, sx, zx, R; status as there).
+ * s / s_rcp: both null, or the consuming Linear's smooth-quant channel scale [H*D] and its reciprocal from
+ * vq_smooth_reciprocal (the division x / s of quant_layer.py:140 exists in reciprocal form only in this kernel).
+ * o: nullable, dense [B*T*S, H*D] fp16 copy of the attention output for callers that need both.
  * H <= 16, T <= 16, H*D % 16 == 0, Kp % 128 == 0. */
-int vq_attn_temporal_rowquant(const void* q, const void* k, const void* v, int8_t* xq, float* sx, int32_t* zx,
-                              int32_t* R, int32_t* status, void* o, int B, int T, int S, int H, int D,
-                              long ld_in, int Kp, float scale, void* stream);
+int vq_attn_temporal_rowquant(const void* q, const void* k, const void* v, const float* s, const float* s_rcp,
+                              int8_t* xq, float* sx, int32_t* zx, int32_t* R, int32_t* status, void* o, int B, int T,
+                              int S, int H, int D, long ld_in, int Kp, float scale, void* stream);
 
 /* ---- small fused elementwise helpers ---------------------------------------
  * mod[j, b, c] = table[j, c] + t0[b, j*C + c]  (stdit.py:100-102), fp32 out, chunk-major. */

@@ -485,6 +485,12 @@ def test_attn_temporal_rowquant_equals_two_kernels(ops, dev, T, S, H, D):
     # without the optional fp16 copy: same codes
     got2 = ops.attn_temporal_rowquant(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], 1, T, S, H, D, 3 * Cc)
     assert torch.equal(got2.xq, got.xq) and torch.equal(got2.R, got.R) and torch.equal(got2.sx, got.sx)
+    # behind the consuming Linear's smoothing vector (the W4A8 plans): = vq_rowquant(o, s) with the IEEE division
+    sm = torch.exp(torch.randn(Cc, generator=torch.Generator().manual_seed(3)) * 0.6).float().to(dev)
+    got3 = ops.attn_temporal_rowquant(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], 1, T, S, H, D, 3 * Cc, s=sm)
+    ref3 = ops.rowquant(o.view(1, T * S, Cc), s=sm, fast_div=False)
+    for f in ("xq", "sx", "zx", "R"):
+        assert torch.equal(getattr(got3, f), getattr(ref3, f)), f
 
 
 # ----------------------------------------------------------------------------- small fused helpers

@@ -412,6 +412,8 @@ struct TempQArgs {
     int32_t* R;
     int32_t* status;
     half_t* o;                                     // nullable: also store the fp16 attention output [B*T*S, H*D]
+    const float* s;                                // nullable [H*D]: smooth-quant channel scale of the consuming Linear
+    const float* s_rcp;                            //                 and its reciprocal (vq_smooth_reciprocal)
     long ld_in;
     int B, T, S, H, Kp;
     float c;
@@ -552,14 +554,7 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
             oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             // this lane: token tq, dims 16*dt + 4*g4 + r, rounded to fp16 like the stored tensor
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float y = (float)(half_t)(oacc[dt][r] * inv_p);
-                oacc[dt][r] = y;
-                if (dt * 16 + 4 * g4 < D) {
-                    vmin = fminf(vmin, y);
-                    vmax = fmaxf(vmax, y);
-                }
-            }
+            for (int r = 0; r < 4; ++r) oacc[dt][r] = (float)(half_t)(oacc[dt][r] * inv_p);
         }
         if (a.o && tq < a.T) {                     // optional fp16 copy (tests, callers that need both)
             half_t* orow = a.o + (((long)b * a.T + tq) * a.S + s) * C + wave * D;
@@ -571,6 +566,25 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ov[r] = (half_t)oacc[dt][r];
                     *reinterpret_cast<half4*>(orow + d0) = ov;
+                }
+            }
+        }
+        // the quantizer's input: the fp16 output, divided by the consuming Linear's smoothing vector when it has one
+        // (x / s, quant_layer.py:140; reciprocal form, bit-identical to the IEEE quotient - vq_common.h)
+#pragma unroll
+        for (int dt = 0; dt < KS; ++dt) {
+            const int d0 = dt * 16 + 4 * g4;
+            if (d0 < D) {
+                if (a.s) {                         // kernel-uniform
+                    const float4v s4 = *reinterpret_cast<const float4v*>(a.s + wave * D + d0);
+                    const float4v r4 = *reinterpret_cast<const float4v*>(a.s_rcp + wave * D + d0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[dt][r] = rq_div_rcp(oacc[dt][r], s4[r], r4[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vmin = fminf(vmin, oacc[dt][r]);
+                    vmax = fmaxf(vmax, oacc[dt][r]);
                 }
             }
         }
@@ -1581,15 +1595,16 @@ static int launch_temporal_quant(const TempQArgs& a, hipStream_t st) {
     return vq_check_launch();
 }
 
-extern "C" int vq_attn_temporal_rowquant(const void* q, const void* k, const void* v, int8_t* xq, float* sx, int32_t* zx,
-                                         int32_t* R, int32_t* status, void* o, int B, int T, int S, int H, int D,
-                                         long ld_in, int Kp, float scale, void* stream) {
+extern "C" int vq_attn_temporal_rowquant(const void* q, const void* k, const void* v, const float* s, const float* s_rcp,
+                                         int8_t* xq, float* sx, int32_t* zx, int32_t* R, int32_t* status, void* o, int B,
+                                         int T, int S, int H, int D, long ld_in, int Kp, float scale, void* stream) {
     if (!q || !k || !v || !xq || !sx || !zx || !R) return VQ_EINVAL;
+    if ((s != nullptr) != (s_rcp != nullptr)) return VQ_EINVAL;     // the division exists in reciprocal form only here
     if (B <= 0 || T <= 0 || S <= 0 || H <= 0) return VQ_EINVAL;
     const int C = H * D;
     if (T > 16 || H > 16 || ld_in % 8 != 0 || B > 65535 || C % 16 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
-    if (3 * 16 * (C / 8) > 7 * 64 * H) return VQ_ESHAPE;          // staging registers of the kernel
-    TempQArgs a{(const half_t*)q, (const half_t*)k, (const half_t*)v, xq, sx, zx, R, status, (half_t*)o, ld_in, B, T, S, H, Kp,
+    if (16 * (C / 8) > 3 * 64 * H || D % 4 != 0) return VQ_ESHAPE;   // V staging registers of the kernel
+    TempQArgs a{(const half_t*)q, (const half_t*)k, (const half_t*)v, xq, sx, zx, R, status, (half_t*)o, s, s_rcp, ld_in, B, T, S, H, Kp,
                 scale * ATT_LOG2E};
     hipStream_t st = (hipStream_t)stream;
     switch (D) {

@@ -53,17 +53,6 @@ __device__ __forceinline__ uint32_t rq_quant8(const float v[8], float inv, float
     return rq_quant8_t<false>(v, inv, delta, zp, qmax, flip, packed);
 }
 
-// x / s with the reciprocal r = RN(1 / s) precomputed per channel (vq_smooth_reciprocal): q = x r, e = x - q s (exact
-// through the fma), q' = q + e r is the correctly rounded quotient (Markstein's theorem) provided s is a normal number
-// whose significand is not all ones and nothing under/overflows on the way.  vq_smooth_reciprocal counts the channels
-// outside the precondition and the host then passes no reciprocal (IEEE division below, ~4x the instructions).
-// The one visible difference: -0 / s comes out as +0 (e = +0 absorbs the sign); no output of a quantizer depends on it.
-__device__ __forceinline__ float rq_div_rcp(float a, float b, float rb) {
-    const float q = a * rb;
-    const float e = __builtin_fmaf(-q, b, a);
-    return __builtin_fmaf(e, rb, q);
-}
-
 // ---------------------------------------------------------------------------
 // plain per-token quantizer, B == 1
 // ---------------------------------------------------------------------------

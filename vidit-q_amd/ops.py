@@ -460,10 +460,17 @@ def attn_temporal(q, k, v, o, B, T, S, H, D, ld_in, ld_out, scale: Optional[floa
 
 
 def attn_temporal_rowquant(q, k, v, B, T, S, H, D, ld_in, scale: Optional[float] = None,
-                           status: Optional[torch.Tensor] = None, o: Optional[torch.Tensor] = None) -> QAct:
+                           status: Optional[torch.Tensor] = None, o: Optional[torch.Tensor] = None,
+                           s: Optional[torch.Tensor] = None) -> Optional[QAct]:
     """Temporal attention + the consuming Linear's per-token 8-bit dynamic quantizer in one kernel (B == 1 per
     forward: per-token scales are shared over the batch otherwise).  Returns what
-    ``rowquant(attn_temporal(...).view(1, T*S, H*D))`` returns, bit for bit."""
+    ``rowquant(attn_temporal(...).view(1, T*S, H*D), s=s)`` returns, bit for bit.  ``s``: the consuming Linear's
+    smoothing vector; None is returned (caller runs the two kernels) when its reciprocal form is not available."""
+    s_rcp = None
+    if s is not None:
+        s_rcp = smooth_rcp(s)
+        if s_rcp is None:
+            return None
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         if not t.is_cuda or t.dtype != torch.float16:
             raise VQError("%s must be a GPU fp16 tensor" % n)
@@ -481,8 +488,8 @@ def attn_temporal_rowquant(q, k, v, B, T, S, H, D, ld_in, scale: Optional[float]
     if o is not None:
         _req(o, torch.float16, "o")
         assert o.shape == (rows, Cc)
-    check(_L().vq_attn_temporal_rowquant(_p(q), _p(k), _p(v), _p(xq), _p(sx), _p(zx), _p(R), _p(status), _p(o), B, T, S,
-                                         H, D, ld_in, Kp, scale, _stream()), "vq_attn_temporal_rowquant")
+    check(_L().vq_attn_temporal_rowquant(_p(q), _p(k), _p(v), _p(s), _p(s_rcp), _p(xq), _p(sx), _p(zx), _p(R), _p(status),
+                                         _p(o), B, T, S, H, D, ld_in, Kp, scale, _stream()), "vq_attn_temporal_rowquant")
     return QAct(xq, sx, zx, R, Cc, 8)
 
 

@@ -79,14 +79,15 @@ class QuantAttention(nn.Module):
                              ld, S * ld, ld, S * ld, out.stride(0), S * out.stride(0), scale=self.scale)
         return out
 
-    def temporal_quantized(self, qkv: torch.Tensor, B: int, T: int, S: int, status=None):
-        """:meth:`temporal` + the 8-bit dynamic per-token quantizer of the next Linear, one kernel; None when that
-        kernel does not apply (then call :meth:`temporal` and the layer's own quantizer)."""
+    def temporal_quantized(self, qkv: torch.Tensor, B: int, T: int, S: int, status=None, s=None):
+        """:meth:`temporal` + the 8-bit dynamic per-token quantizer of the next Linear (behind its smoothing vector
+        ``s`` when it has one), one kernel; None when that kernel does not apply (then call :meth:`temporal` and the
+        layer's own quantizer)."""
         C = self.num_heads * self.head_dim
         if B != 1 or T > 16 or self.num_heads > 16 or C % 16 != 0 or self.head_dim not in (16, 32, 64, 72):
             return None
         return ops.attn_temporal_rowquant(qkv, qkv[:, C:], qkv[:, 2 * C:], B, T, S, self.num_heads, self.head_dim,
-                                          qkv.stride(0), scale=self.scale, status=status)
+                                          qkv.stride(0), scale=self.scale, status=status, s=s)
 
     def cross(self, q: torch.Tensor, kv: torch.Tensor, kv_off: torch.Tensor, B: int, Nq: int,
               out: Optional[torch.Tensor] = None):

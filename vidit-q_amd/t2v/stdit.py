@@ -467,9 +467,9 @@ class STDiTBlock(nn.Module):
             qas = [l.quantize_input(x3, s, add_rows=tpe2, add_div=S) for l, s in zip((a2.q, a2.k, a2.v), svs)]
         qkv = qkv_proj(a2, qas)
         qa = None
-        if _ATTN_QUANT and svec(a2.proj) is None and isinstance(a2.proj.act_quantizer, DynamicActQuantizer) \
-                and a2.proj.act_quantizer.n_bits == 8:
-            qa = a2.core.temporal_quantized(qkv, B, T, S, status=a2.proj.status)   # attention + proj's quantizer
+        if _ATTN_QUANT and isinstance(a2.proj.act_quantizer, DynamicActQuantizer) and a2.proj.act_quantizer.n_bits == 8:
+            # attention + proj's quantizer (behind proj's smoothing vector, if any) in one kernel
+            qa = a2.core.temporal_quantized(qkv, B, T, S, status=a2.proj.status, s=svec(a2.proj))
         if qa is None:
             att_o = a2.core.temporal(qkv, B, T, S, out=att_o)
             qa = a2.proj.quantize_input(att_o.view(B, N, C), svec(a2.proj))
