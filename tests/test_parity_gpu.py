@@ -475,6 +475,50 @@ def test_sample_sharded_world1_equals_per_prompt_loops(dev, ops):
         assert torch.equal(out[0], full[i])
 
 
+def test_quantize_and_distribute_over_a_one_rank_rccl_group(dev, ops):
+    """The multi-GPU set-up path on ONE device: a one-rank NCCL (= RCCL) process group, rank 0 packs straight into the
+    broadcast arena, the broadcast and install run on device buffers, gather_latents goes through all_gather - and the
+    model computes exactly what the world-1 shortcut computes."""
+    import socket
+    import torch.distributed as dist
+    import viditq_amd  # noqa
+    from viditq_amd import shard, synth
+    from viditq_amd.config import loads_yaml
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        outs = []
+        for force in (True, False):
+            m = synth.build_stdit(dev, depth=2, hidden_size=64, num_heads=4, input_size=(4, 8, 8), model_max_length=12,
+                                  caption_channels=32, seed=0)
+            cfg = loads_yaml(synth.W4A8_TIMESTEP_AWARE)      # smooth-quant statistics travel in the broadcast as well
+            cfg.quant.activation.quantizer["n_spatial_token"], cfg.quant.activation.quantizer["n_temporal_token"] = 16, 4
+            qnn = shard.quantize_and_distribute(m, cfg, 0, 1, force_collective=force)
+            if force:
+                assert getattr(qnn, "_packed_arena", None) is not None
+            embeds, _ = synth.synthetic_prompts(1, dev, model_max_length=12, caption_channels=32)
+            z = synth.synthetic_latent(0, z_size=(4, 4, 8, 8), seed=42, device=dev).half()
+            y = embeds["y"][0:1].permute(1, 0, 2, 3, 4).reshape(2, 1, 12, 32)
+            t = torch.full((1,), 721, device=dev, dtype=torch.long)
+            with torch.no_grad():
+                outs.append(qnn(z, t, y[:1], mask=embeds["mask"][0:1], timestep_id=721).float())
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+        x = torch.randn(2, 4, 4, 8, 8, device=dev)
+        torch.cuda.synchronize()
+        # world-1 group, forced through the collective: identity
+        pad = [torch.empty_like(x)]
+        dist.all_gather(pad, x)
+        assert torch.equal(pad[0], x)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _sharded_worker(rank, world, port, ret):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

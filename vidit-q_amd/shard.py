@@ -171,10 +171,12 @@ def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None, 
     return int(nbytes)
 
 
-def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.REMAIN_FP) -> QuantModel:
+def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.REMAIN_FP,
+                            force_collective: bool = False) -> QuantModel:
     """Every rank wraps its (identically seeded / loaded) fp16 model; rank 0 runs weight PTQ and packs;
-    the result reaches the other ranks by ONE broadcast."""
-    if world == 1:
+    the result reaches the other ranks by ONE broadcast.  ``force_collective``: take the arena + broadcast route at
+    world 1 too (a one-rank process group: how the RCCL calls are exercised on a single device)."""
+    if world == 1 and not force_collective:
         qnn = synth.quantize_model(model, cfg, fp_layers)
         prepack(qnn)
         return qnn
