@@ -168,6 +168,116 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// smoothed per-token quantizer for LONG rows (C up to 4608: the fc2 input of the smooth-quant plans, optionally behind
+// GELU): rowquant_fast_kernel<9, true> read the smoothing vector and its reciprocal from global memory for every row -
+// 36.9 KB through the L1 per 9.2 KB row - and ran 69 us where the un-smoothed kernel takes 44.  Here a workgroup
+// stages s and 1/s in LDS once and its waves walk rows grid-stride (next row's data requested before the current one
+// is processed).  Same arithmetic in the same order as rowquant_fast_kernel's reciprocal path: bit-identical outputs.
+// ---------------------------------------------------------------------------
+template <int MAXCH, bool GELU>
+__global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
+    const half_t* __restrict__ x, const float* __restrict__ s, const float* __restrict__ s_rcp, int8_t* __restrict__ xq,
+    float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R, int n_tok, int C, int Kp, int n_bits,
+    int32_t* status) {
+    extern __shared__ __attribute__((aligned(16))) float rq_lds[];
+    float* ls = rq_lds;
+    float* lr = rq_lds + C;
+    for (int c = threadIdx.x * 4; c < C; c += RQF_THREADS * 4) {
+        *reinterpret_cast<float4v*>(ls + c) = *reinterpret_cast<const float4v*>(s + c);
+        *reinterpret_cast<float4v*>(lr + c) = *reinterpret_cast<const float4v*>(s_rcp + c);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int cx = (n_bits == 8) ? 128 : 0;
+    const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
+    const int stride = gridDim.x * RQF_WAVES;
+    int tok = blockIdx.x * RQF_WAVES + (threadIdx.x >> 6);
+    half8 hn[MAXCH];
+    if (tok < n_tok) {
+        const half_t* row = x + (size_t)tok * C;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i)
+            if (lane * 8 + i * 512 < C) hn[i] = *reinterpret_cast<const half8*>(row + lane * 8 + i * 512);
+    }
+    for (; tok < n_tok; tok += stride) {
+        float w[MAXCH][8];
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i)
+            if (lane * 8 + i * 512 < C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[i][e] = GELU ? (float)(half_t)rq_gelu_tanh((float)hn[i][e]) : (float)hn[i][e];
+            }
+        if (tok + stride < n_tok) {                        // next row in flight under this row's arithmetic
+            const half_t* row = x + (size_t)(tok + stride) * C;
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i)
+                if (lane * 8 + i * 512 < C) hn[i] = *reinterpret_cast<const half8*>(row + lane * 8 + i * 512);
+        }
+        float vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c0 = lane * 8 + i * 512;
+            if (c0 < C) {
+                float sv[8], rv[8];
+                *reinterpret_cast<float4v*>(sv) = *reinterpret_cast<const float4v*>(ls + c0);
+                *reinterpret_cast<float4v*>(sv + 4) = *reinterpret_cast<const float4v*>(ls + c0 + 4);
+                *reinterpret_cast<float4v*>(rv) = *reinterpret_cast<const float4v*>(lr + c0);
+                *reinterpret_cast<float4v*>(rv + 4) = *reinterpret_cast<const float4v*>(lr + c0 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    w[i][e] = rq_div_rcp(w[i][e], sv[e], rv[e]);
+                    vmin = fminf(vmin, w[i][e]);
+                    vmax = fmaxf(vmax, w[i][e]);
+                }
+            }
+        }
+        vmin = wave_min_f(vmin);
+        vmax = wave_max_f(vmax);
+        float delta, zp;
+        bool small;
+        vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+        if (small && lane == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
+        const float inv = __fdiv_rn(1.0f, delta);
+        const int izx = (int)zp - cx;
+        int8_t* qrow = xq + (size_t)tok * Kp;
+        uint32_t csum = 0;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int c0 = lane * 8 + i * 512;
+            if (c0 < C) {
+                uint2 p;
+                csum += rq_quant8(w[i], inv, delta, zp, qmax, flip, p);
+                *reinterpret_cast<uint2*>(qrow + c0) = p;
+            } else if (c0 < Kp) {
+                *reinterpret_cast<uint2*>(qrow + c0) = make_uint2(0u, 0u);
+            }
+        }
+        const int rs = wave_sum_i((int)csum) - cx * C;
+        if (lane == 0) {
+            sx[tok] = delta;
+            zx[tok] = izx;
+            R[tok] = rs - C * izx;
+        }
+    }
+}
+
+template <bool GELU>
+static bool launch_rq_smooth_lds(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
+                                 int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+    if (C % 8 != 0 || C <= 1536 || C > 4608) return false;
+    const int lds = 2 * C * (int)sizeof(float);
+    auto k = rowquant_smooth_lds_kernel<9, GELU>;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              2 * 4608 * (int)sizeof(float));
+    if (e != hipSuccess) return false;
+    int grid = (n_tok + RQF_WAVES - 1) / RQF_WAVES;
+    if (grid > 1024) grid = 1024;                          // 4 workgroups of 36.9 KB LDS per CU; rows grid-stride
+    hipLaunchKernelGGL(k, dim3(grid), dim3(RQF_THREADS), lds, st, x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // plain per-token quantizer, TWO rows per wave (C % 128 == 0, C <= 1536, no smoothing / added rows).
 // At C = 1152 the one-row-per-wave kernel above is VALU-bound, and half of its VALU work is per ROW, not per
 // element (two DPP reductions, three IEEE divisions for delta / 1/delta / zp, the row-sum reduction), with a
@@ -660,6 +770,9 @@ bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, cons
                       int32_t* status, hipStream_t st) {
     if (C > 4608 || Kp > 4608) return false;
     const bool hs = s != nullptr, ha = add_rows != nullptr;
+    if (hs && s_rcp && !ha && !zpf && C > 1536 && n_tok >= 64 &&
+        launch_rq_smooth_lds<false>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st))
+        return true;
     if (hs && s_rcp && !ha && !zpf && C % 128 == 0 && Kp == C && C >= 768 && C <= 1280 && n_tok >= 2) {
         LnqFastOut o{};
         o.s[0] = s, o.r[0] = s_rcp, o.xq[0] = xq, o.sx[0] = sx, o.zx[0] = zx, o.R[0] = R;
@@ -704,6 +817,9 @@ static void launch_lnq(int n_out, dim3 grid, hipStream_t st, const half_t* x, co
 bool vq_gelu_rowquant_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
                            int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
     if (C > 4608 || Kp > 4608) return false;
+    if (s && s_rcp && C > 1536 && n_tok >= 64 &&
+        launch_rq_smooth_lds<true>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st))
+        return true;
     dim3 grid((n_tok + RQF_WAVES - 1) / RQF_WAVES), block(RQF_THREADS);
 #define RQG_GO(M_, S_)                                                                                            \
     hipLaunchKernelGGL((rowquant_fast_kernel<M_, S_, false, true>), grid, block, 0, st, x, (const half_t*)nullptr, 1, s, \
