@@ -365,6 +365,42 @@ def test_attn_fwd_self(ops, dev, n_seq, L, H, D):
     assert (o.cpu().float() - ref).abs().max() < 4e-3
 
 
+@pytest.mark.parametrize("n_seq,Lq,Lk,H,D", [(2, 300, 333, 3, 72), (1, 257, 129, 2, 72), (3, 192, 1000, 2, 64), (2, 513, 191, 4, 32),
+                                             (1, 700, 260, 5, 16), (2, 256, 8192, 1, 72)])
+def test_attn_fwd_long_ragged_rectangular(ops, dev, n_seq, Lq, Lk, H, D):
+    """The long-sequence kernel (LDS-DMA tiles, zero-filled rows past the last key, masked ragged key tiles, partial
+    query tiles) on query / key lengths that are neither equal nor multiples of the 64-key tile or the 256-query
+    workgroup, every head dim it is instantiated for, and a key sequence long enough for 128 tiles."""
+    Cc = H * D
+    q = h16(n_seq * Lq, Cc, scale=1.0, seed=Lq + D).to(dev)
+    kv = h16(n_seq * Lk, 2 * Cc, scale=1.0, seed=Lk + D).to(dev)
+    o = torch.full((n_seq * Lq, Cc), float("nan"), dtype=torch.float16, device=dev)
+    ops.attn_fwd(q, kv, kv[:, Cc:], o, n_seq, Lq, Lk, H, D, Lq * Cc, Cc, Lk * 2 * Cc, 2 * Cc, Lq * Cc, Cc)
+    ref = _attn_ref(q.cpu().reshape(n_seq, Lq, H, D), kv[:, :Cc].cpu().reshape(n_seq, Lk, H, D),
+                    kv[:, Cc:].cpu().reshape(n_seq, Lk, H, D), D ** -0.5).reshape(n_seq * Lq, Cc)
+    assert torch.isfinite(o).all()
+    assert rel_l2(o.cpu().float(), ref) < 1e-3
+    assert (o.cpu().float() - ref).abs().max() < 4e-3
+
+
+@pytest.mark.parametrize("D", [16, 32, 64, 72])
+@pytest.mark.parametrize("n_seq,Lq,Lk,H", [(1, 256, 256, 1), (2, 512, 320, 4), (4, 1024, 1024, 16)])
+def test_attn_fwd_constant_values_come_back_exactly(ops, dev, D, n_seq, Lq, Lk, H):
+    """Size-independent property: with V == 1 every output is exactly 1 whatever the scores are (the row sum and the
+    weighted sum leave the same MFMA).  Repeated launches on fresh random q / k: this is the test that caught an
+    asm consumer reading an MFMA accumulator without wait states (D = 16: garbage running max, rows of 0 / NaN)."""
+    Cc = H * D
+    g = torch.Generator().manual_seed(D + Lq)
+    for _ in range(6):
+        q = torch.randn(n_seq * Lq, Cc, generator=g).half().to(dev)
+        kv = torch.randn(n_seq * Lk, 2 * Cc, generator=g).half()
+        kv[:, Cc:] = 1.0
+        kv = kv.to(dev)
+        o = torch.zeros((n_seq * Lq, Cc), dtype=torch.float16, device=dev)
+        ops.attn_fwd(q, kv, kv[:, Cc:], o, n_seq, Lq, Lk, H, D, Lq * Cc, Cc, Lk * 2 * Cc, 2 * Cc, Lq * Cc, Cc)
+        assert float((o.float() - 1.0).abs().max()) <= 2.0 ** -10
+
+
 def test_attn_fwd_cross_varlen(ops, dev):
     B, Nq, H, D = 3, 200, 4, 72
     Cc = H * D

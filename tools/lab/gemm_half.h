@@ -101,10 +101,10 @@ __global__ __launch_bounds__(512, 4) void gemm_i8_pair_kernel(GemmArgs a) {
                 const unsigned dst = lds0 + stage * STAGE + p * 1024;
                 const int koff = kt * 64;
                 if (p < XP)
-                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_x), "s"(koff)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_x), "s"(koff)
                                  : "memory", "m0");
                 else
-                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_w), "s"(koff)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_w), "s"(koff)
                                  : "memory", "m0");
             }
         }

@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs 
                     (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem +
                     (isk ? buf * KTB + j * 1024 : 2 * KTB + buf * VT + (j - NKI) * 1024));
                 if (ok[i])
-                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff[i]), "s"(rs)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff[i]), "s"(rs)
                                  : "memory", "m0");
             }
         }
@@ -1175,7 +1175,12 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs 
             float mloc;
             {
                 float mx;   // v_max3 chain in asm: fmaxf() would canonicalise every MFMA result first (one extra v_max each)
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
+                // The hazard recognizer does not look at asm operands: an asm VALU read of an accumulator the matrix core
+                // is still writing gets NO wait states and sees the previous contents (with one k-step, D = 16: the last
+                // tile's exponentials - a garbage running max, rows of zeros / NaN).  So the first read of the fresh
+                // accumulator is a compiler-visible VALU instruction (x + 0.0f is not foldable); the asm chain depends on it.
+                const float s0 = s[0] + 0.0f;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s0), "v"(s[1]), "v"(s[2]));
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[r]), "v"(s[r + 1]));
                 asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[15]));

@@ -124,11 +124,11 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
                 const unsigned dst = lds0 + stage * STAGE + p * 1024;
                 if (p < XP) {
                     const int koff = kt * 128;
-                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_x), "s"(koff)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_x), "s"(koff)
                                  : "memory", "m0");
                 } else {
                     const int koff = kt * WROW;
-                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_w), "s"(koff)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_w), "s"(koff)
                                  : "memory", "m0");
                 }
             }
