@@ -1098,7 +1098,9 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs 
                 const bool isk = j < NKI;
                 const uint8_t* b = reinterpret_cast<const uint8_t*>(isk ? kbase : vbase) + t0;
                 // issued through asm: the builtin makes the compiler order every later ds_read behind the DMA (vmcnt(0)
-                // before the first MFMAs of the tile); the only consumer-side wait needed is the one in wg_barrier()
+                // before the first MFMAs of the tile); the only consumer-side wait needed is the one in wg_barrier().
+                // Hazards the recognizer would handle for its own instructions are spelled out: s_nop 4 covers the M0
+                // write -> LDS-DMA rule (1 wait state) and a VALU-written (v_readfirstlane) resource SGPR -> VMEM read (5)
                 const unsigned long ba = (unsigned long)b;
                 const int4v rs = {(int)__builtin_amdgcn_readfirstlane((unsigned)ba),
                                   (int)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
@@ -1107,7 +1109,7 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs 
                     (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem +
                     (isk ? buf * KTB + j * 1024 : 2 * KTB + buf * VT + (j - NKI) * 1024));
                 if (ok[i])
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff[i]), "s"(rs)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff[i]), "s"(rs)
                                  : "memory", "m0");
             }
         }
