@@ -401,6 +401,31 @@ def test_attn_fwd_constant_values_come_back_exactly(ops, dev, D, n_seq, Lq, Lk, 
         assert float((o.float() - 1.0).abs().max()) <= 2.0 ** -10
 
 
+def test_attn_temporal_and_cross_constant_values_come_back_exactly(ops, dev):
+    """The same invariance for the temporal kernel (T = 16 rows per sequence, 1024 sequences), the register-resident
+    cross-attention kernel (<= 128 prompt tokens, ragged per sample) and the first-generation kernel behind kv_off."""
+    g = torch.Generator().manual_seed(3)
+    T, S, H, D = 16, 1024, 16, 72
+    Cc = H * D
+    qkv = torch.randn(T * S, 3 * Cc, generator=g).half()
+    qkv[:, 2 * Cc:] = 1.0
+    qkv = qkv.to(dev)
+    o = torch.zeros((T * S, Cc), dtype=torch.float16, device=dev)
+    ops.attn_temporal(qkv, qkv[:, Cc:], qkv[:, 2 * Cc:], o, 1, T, S, H, D, 3 * Cc, Cc)
+    assert float((o.float() - 1.0).abs().max()) <= 2.0 ** -10
+    B, Nq = 2, 4096
+    lens = [120, 37]
+    q = torch.randn(B * Nq, Cc, generator=g).half().to(dev)
+    kv = torch.randn(sum(lens), 2 * Cc, generator=g).half()
+    kv[:, Cc:] = 1.0
+    kv = kv.to(dev)
+    off = torch.tensor([0, 120, 157], dtype=torch.int32, device=dev)
+    for max_len in (120, 0):                            # bound known -> register kernel; unknown -> generic kernel
+        o = torch.zeros((B * Nq, Cc), dtype=torch.float16, device=dev)
+        ops.attn_fwd(q, kv, kv[:, Cc:], o, B, Nq, max_len, H, D, Nq * Cc, Cc, 0, 2 * Cc, Nq * Cc, Cc, kv_off=off)
+        assert float((o.float() - 1.0).abs().max()) <= 2.0 ** -10, max_len
+
+
 def test_attn_fwd_cross_varlen(ops, dev):
     B, Nq, H, D = 3, 200, 4, 72
     Cc = H * D
