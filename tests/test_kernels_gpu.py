@@ -619,6 +619,36 @@ def test_gemm_i8_batched_equals_separate_launches(ops, dev):
 
 
 @pytest.mark.parametrize("w_bits", [8, 4])
+@pytest.mark.parametrize("N,K", [(1152, 1152), (4608, 1152), (1152, 4608)])
+def test_gemm_full_size_against_the_library_integer_matmul(ops, dev, N, K, w_bits):
+    """BASELINE size (16384 tokens): the int32 contraction of the codes recomputed by the vendor library
+    (torch._int_mm), the rank-one zero-point terms and the dequantisation in plain torch - an independent route to the
+    same numbers.  The fused kernel rounds once (fma) where torch rounds twice, so: at most one fp16 ulp apart, on at
+    most 0.1 % of the outputs."""
+    M = 16384
+    x = h16(1, M, K, scale=1.5, seed=K).to(dev)
+    W = h16(N, K, scale=0.04, seed=N + K).to(dev)
+    b = h16(N, scale=0.1, seed=5).float().to(dev)
+    qa = ops.rowquant(x)
+    d, z = ops.weight_minmax(W, w_bits)
+    pw = ops.pack_weight(W, d, z, w_bits)
+    out = ops.gemm_i8(qa, pw, bias=b).float()
+    if w_bits == 8:
+        ws = pw.wq
+    else:                                              # nibble layout of pack.hip: byte j of a group of 8 k holds
+        g = pw.wq.view(N, pw.Kp // 8, 4).to(torch.int16)    # code[k0 + j] (low) and code[k0 + 4 + j] (high)
+        ws = torch.cat([g & 15, g >> 4], dim=2).reshape(N, pw.Kp).to(torch.int8)
+    acc = torch._int_mm(qa.xq, ws.t().contiguous()).long()
+    tt = acc - pw.zw.long()[None, :] * qa.R.long()[:, None] - qa.zx.long()[:, None] * pw.cs.long()[None, :]
+    assert int(tt.abs().max()) < 2 ** 31
+    ref = ((qa.sx[:, None] * pw.sw[None, :]) * tt.float() + b[None, :]).half().float()
+    diff = (out - ref).abs()
+    ulp = 2.0 ** -10 * ref.abs().clamp(min=2.0 ** -14)
+    assert bool((diff <= ulp).all())
+    assert float((diff > 0).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("w_bits", [8, 4])
 @pytest.mark.parametrize("M,G", [(600, 3), (1024, 2), (77, 3)])
 def test_gemm_i8_grouped_equals_separate_launches(ops, dev, w_bits, M, G):
     """vq_gemm_i8_grouped: the q / k / v Linears of a plan with one smoothing vector per Linear (three quantized copies
