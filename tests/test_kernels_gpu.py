@@ -54,6 +54,21 @@ def test_rowquant_bit_exact(ops, dev, B, n_tok, C, n_bits):
     assert int(st.item()) == 0
 
 
+@pytest.mark.parametrize("C", [1152, 4608])
+def test_rowquant_full_size_bit_exact(ops, dev, C):
+    """BASELINE size: all 16384 token rows of a block input against the oracle quantizer (codes, grid, row terms)."""
+    n_tok = 16384
+    x = h16(1, n_tok, C, scale=2.0, seed=C)
+    codes, dq, delta, zp, eps = fq.dyn_act_quant(x.float(), 8)
+    assert not eps
+    qa = ops.rowquant(x.to(dev), want_zp=True)
+    assert torch.equal(qa.xq[:, :C].cpu().int() + 128, codes.int().reshape(n_tok, C))
+    assert torch.equal(qa.sx.cpu(), delta.reshape(-1)) and torch.equal(qa.zpf.cpu(), zp.reshape(-1))
+    zx = zp.reshape(-1).int() - 128
+    assert torch.equal(qa.zx.cpu(), zx)
+    assert torch.equal(qa.R.cpu(), (codes.int().reshape(n_tok, C) - 128).sum(-1) - C * zx)
+
+
 def test_rowquant_smooth_and_add(ops, dev):
     B, T, S, C = 2, 4, 8, 96
     x = h16(B, T * S, C, scale=2.0, seed=3)
