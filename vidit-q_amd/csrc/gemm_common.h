@@ -231,8 +231,12 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
     const int row0 = lane / CPR, cc0 = lane - row0 * CPR;
     const int step_g = QS * ldb + RS * 16, wrap_g = ldb - CPR * 16;   // + wrap_g when the column wraps
     constexpr int step_s = QS * ROWB + RS * 16, wrap_s = ROWB - CPR * 16;
+    // Two half passes (rows 0..WTM/2-1, then the rest): the stores of the first half are in flight while the second half
+    // is dequantised, instead of all VALU work first and all stores after it.
+    constexpr int NH = (TM % 2 == 0 && NITER % 2 == 0 && ((WTM / 2) * CPR) % 64 == 0) ? 2 : 1;
+    constexpr int TMH = TM / NH, NITH = NITER / NH;
     // the residual operand: requested during the dequant phase (its HBM latency hides under the VALU work)
-    half8 rres[HAS_RES ? NITER : 1];
+    half8 rres[HAS_RES ? NITH : 1];
     int pcc = cc0;
     uint32_t pgo = (uint32_t)(row0 * ldb + cc0 * 16);
     auto fetch_res = [&](int it) {
@@ -241,16 +245,19 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
         pcc += w ? RS - CPR : RS;
         pgo += w ? step_g + wrap_g : step_g;
     };
-    {
-        float sxm[TM];
-        int nzx[TM], Rm[TM];
+    float sxm[TM];
+    int nzx[TM], Rm[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rl = wm * WTM + i * 16 + frow;
-            sxm[i] = l_sx[rl];
-            nzx[i] = l_nzx[rl];
-            Rm[i] = l_R[rl];
-        }
+    for (int i = 0; i < TM; ++i) {
+        const int rl = wm * WTM + i * 16 + frow;
+        sxm[i] = l_sx[rl];
+        nzx[i] = l_nzx[rl];
+        Rm[i] = l_R[rl];
+    }
+    int cc = cc0;
+    uint32_t go = (uint32_t)(row0 * ldb + cc0 * 16), so = (uint32_t)(row0 * ROWB + cc0 * 16);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = wn * WTN + j * 16 + 4 * fc;
@@ -259,7 +266,7 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
             const int4v ics = *reinterpret_cast<const int4v*>(l_cs + nl);
             const float4v fb = *reinterpret_cast<const float4v*>(l_b + nl);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int i = h * TMH; i < (h + 1) * TMH; ++i) {
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -273,33 +280,32 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
                 *reinterpret_cast<half4*>(slab + (i * 16 + frow) * ROWB + (j * 16 + 4 * fc) * 2) = o;
             }
             if constexpr (HAS_RES) {
-                constexpr int PER = (NITER + TN - 1) / TN;
+                constexpr int PER = (NITH + TN - 1) / TN;
 #pragma unroll
                 for (int u = 0; u < PER; ++u)
-                    if (j * PER + u < NITER) fetch_res(j * PER + u);
+                    if (j * PER + u < NITH) fetch_res(j * PER + u);
             }
         }
-    }
-    // store pass: this wave's slab as row-major 16-byte chunks (same wave wrote it: LDS operations are in order)
-    int cc = cc0;
-    uint32_t go = (uint32_t)(row0 * ldb + cc0 * 16), so = (uint32_t)(row0 * ROWB + cc0 * 16);
+        // store pass of this half: the wave's slab rows as row-major 16-byte chunks (same wave wrote them: LDS
+        // operations are in order)
 #pragma unroll
-    for (int it = 0; it < NITER; ++it) {
-        half8 y = *reinterpret_cast<const half8*>(slab + so);
-        if constexpr (HAS_RES) {
-            const half8 rr = rres[it];
+        for (int it = 0; it < NITH; ++it) {
+            half8 y = *reinterpret_cast<const half8*>(slab + so);
+            if constexpr (HAS_RES) {
+                const half8 rr = rres[it];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const half2v s2 = half2v{y[2 * q], y[2 * q + 1]} + half2v{rr[2 * q], rr[2 * q + 1]};
-                y[2 * q] = s2[0];
-                y[2 * q + 1] = s2[1];
+                for (int q = 0; q < 4; ++q) {
+                    const half2v s2 = half2v{y[2 * q], y[2 * q + 1]} + half2v{rr[2 * q], rr[2 * q + 1]};
+                    y[2 * q] = s2[0];
+                    y[2 * q + 1] = s2[1];
+                }
             }
+            *reinterpret_cast<half8*>(obase + go) = y;
+            const bool w = cc >= CPR - RS;
+            cc += w ? RS - CPR : RS;
+            go += w ? step_g + wrap_g : step_g;
+            so += w ? step_s + wrap_s : step_s;
         }
-        *reinterpret_cast<half8*>(obase + go) = y;
-        const bool w = cc >= CPR - RS;
-        cc += w ? RS - CPR : RS;
-        go += w ? step_g + wrap_g : step_g;
-        so += w ? step_s + wrap_s : step_s;
     }
 }
 
