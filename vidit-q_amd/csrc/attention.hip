@@ -1088,13 +1088,13 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs 
         ok[i] = j < NI && piece < C::CHD;
         voff[i] = row * strideB + piece * 16;
     }
-    auto issue = [&](int kt) __attribute__((always_inline)) {
+    auto issue = [&](int kt, int part = -1) __attribute__((always_inline)) {   // part 0: round i == 0, 1: the others, -1: all
         const unsigned t0 = (unsigned)kt * (unsigned)KT * (unsigned)strideB;
         const int buf = kt & 1;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
             const int j = wave + NW * i;
-            if (j < NI) {
+            if (j < NI && (part < 0 || (part == 0) == (i == 0))) {
                 const bool isk = j < NKI;
                 const uint8_t* b = reinterpret_cast<const uint8_t*>(isk ? kbase : vbase) + t0;
                 // issued through asm: the builtin makes the compiler order every later ds_read behind the DMA (vmcnt(0)
@@ -1134,7 +1134,6 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs 
         constexpr bool RAG = decltype(rag_tag)::value;
         const uint8_t* kt_ = smem + (kt & 1) * KTB + l31 * C::KROW;
         const uint8_t* vt_ = smem + 2 * KTB + (kt & 1) * VT + vtr0;
-        if (!(ABLD & 1) && kt + 1 < nkt) issue(kt + 1);     // into the buffers whose last readers passed the previous barrier
 #pragma unroll
         for (int sc = 0; sc < KT / 32; ++sc) {
             float16v s;
@@ -1169,6 +1168,12 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs 
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // next tile's DMA into the buffers whose last readers passed the previous barrier: issued behind the QK^T
+            // chains of the first two half tiles, so that the MFMAs of a tile start right after the barrier and the DMA
+            // issue (~100 cycles per piece) sits in the waits for those chains' results
+            // (in two instalments: A/B on one box 112.0-115.5 vs 115.3-118.0 us at 16 x 1024, 112 vs 122 us at 1 x 4096
+            //  against all pieces behind the first chain; at the top of the tile, before any MFMA: 122.7 us)
+            if (sc < 2 && !(ABLD & 1) && kt + 1 < nkt) issue(kt + 1, sc);
             if constexpr (RAG) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
