@@ -1358,7 +1358,10 @@ __global__ __launch_bounds__(512) void attn_cross_reg_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int key = (2 * kp + (e >> 2)) * 16 + 4 * g4 + (e & 3);
-                vf[dt][kp][e] = d < D ? *reinterpret_cast<const half_t*>(vreg + key * VROWB + d * 2) : (half_t)0.f;
+                // dim D (= 72, inside the zero-padded fifth tile) is a row of ones: the softmax row sum then comes out
+                // of the P.V MFMAs (O^T row D) instead of 32 adds per sub-tile
+                vf[dt][kp][e] = d < D ? *reinterpret_cast<const half_t*>(vreg + key * VROWB + d * 2)
+                                      : (d == D ? (half_t)1.f : (half_t)0.f);
             }
     }
 
@@ -1410,26 +1413,38 @@ __global__ __launch_bounds__(512) void attn_cross_reg_kernel(AttnArgs a) {
         m = fmaxf(m, __shfl_xor(m, 32));
         const float m_use = (m == -INFINITY) ? 0.f : m;
         const float nmc = -m_use * a.c;                // exp2(s*c - m*c): one fma per score instead of sub + mul
-        float psum = 0.f;
         half8 pf[4];
+        {
+            typedef float float2v __attribute__((ext_vector_type(2)));
+            const float2v cc2 = {a.c, a.c}, nm2 = {nmc, nmc};
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], a.c, nmc));
-                psum += p;
-                pf[kt >> 1][(kt & 1) * 4 + r] = (half_t)p;
-            }
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
-        const float inv = psum > 0.f ? __fdiv_rn(1.0f, psum) : 0.f;
+                for (int r = 0; r < 4; r += 2) {
+                    const float2v t = __builtin_elementwise_fma(float2v{sc[kt][r], sc[kt][r + 1]}, cc2, nm2);   // v_pk_fma_f32
+                    pf[kt >> 1][(kt & 1) * 4 + r] = (half_t)__builtin_amdgcn_exp2f(t[0]);
+                    pf[kt >> 1][(kt & 1) * 4 + r + 1] = (half_t)__builtin_amdgcn_exp2f(t[1]);
+                }
+        }
         const int qi = st * 16 + lq;
         half_t* orow = oseq + (long)qi * a.o_tok_stride;
+        // fifth dim tile first: its row D - 64 = 8 (lane group g4 = 2, register 0) is the row sum of this lane's query
+        float inv;
+        float4v o4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) o4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[4][kp], pf[kp], o4, 0, 0, 0);
+        {
+            const float psum = __shfl(o4[0], lq + 32);
+            inv = psum > 0.f ? __fdiv_rn(1.0f, psum) : 0.f;
+        }
 #pragma unroll
         for (int dt = 0; dt < 5; ++dt) {
-            float4v o = {0.f, 0.f, 0.f, 0.f};
+            float4v o = o4;
+            if (dt < 4) {
+                o = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kp = 0; kp < 4; ++kp) o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt][kp], pf[kp], o, 0, 0, 0);
+                for (int kp = 0; kp < 4; ++kp) o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dt][kp], pf[kp], o, 0, 0, 0);
+            }
             const int d0 = dt * 16 + 4 * g4;
             if (d0 < D && qi < a.Lq) {
                 half4 ov;
