@@ -31,6 +31,34 @@ def test_header_symbols_are_exported_and_bound():
     assert b"shape" in lib.vq_strerror(-2)
 
 
+def test_ctypes_signatures_have_the_headers_arity_and_kinds():
+    """Every binding in _lib.SIGNATURES has exactly the parameter count of its declaration in include/viditq.h, and
+    pointer / integer / float kinds agree position by position (an ABI edit that forgets the binding - or the other
+    way round - would otherwise pass garbage without any error)."""
+    import ctypes as C
+    import viditq_amd  # noqa: F401
+    from viditq_amd import _lib
+    src = open(os.path.join(ROOT, "include", "viditq.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = dict((m.group(1), m.group(2)) for m in re.finditer(r"\b(vq_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
+    assert set(decls) == set(_lib.SIGNATURES)
+    for name, params in decls.items():
+        params = " ".join(params.split())
+        plist = [] if params in ("", "void") else [q.strip() for q in params.split(",")]
+        _, argtypes = _lib.SIGNATURES[name]
+        assert len(plist) == len(argtypes), "%s: header has %d parameters, binding %d" % (name, len(plist), len(argtypes))
+        for i, (decl, ct) in enumerate(zip(plist, argtypes)):
+            if "*" in decl:
+                kind = C.c_void_p
+            elif re.match(r"^(const\s+)?float\b", decl):
+                kind = C.c_float
+            elif re.match(r"^(const\s+)?long\b", decl):
+                kind = C.c_long
+            else:
+                kind = C.c_int
+            assert ct is kind, "%s parameter %d (%s): bound as %s" % (name, i, decl, ct.__name__)
+
+
 def test_argument_validation_without_gpu():
     """Entry points reject bad arguments before touching the device (error behaviour of the ABI)."""
     import viditq_amd  # noqa: F401
