@@ -6,6 +6,7 @@
 //   20/21 half-CU workgroups                       100+  ablations / cycle stamps of the shipping kernel (variant 11)
 // What each one taught is in DESIGN.md (5).  The shipping kernels live in vidit-q_amd/csrc/gemm_i8.hip.
 #include "../../vidit-q_amd/csrc/gemm_wide.h"
+#include "../../vidit-q_amd/csrc/gemm_pp.h"
 #include "gemm_half.h"
 
 int g_vq_last_hip_error = 0;
@@ -1415,6 +1416,32 @@ extern "C" int vq_lab_gemm_i8(const int8_t* xq, const float* sx, const int32_t* 
             return launch_gemm_wide<256, 288, 4, 2, false>(a, st);
         default:
             break;
+    }
+    if (variant >= 200 && variant < 216 && w_bits > 4 && gemm_pp_covers(a)) {
+        // profiling ablations of the product ping-pong kernel (csrc/gemm_pp.h; static unit walk; results wrong
+        // unless the ablation mask is 0): 1 no LDS-DMA after the prologue, 2 no MFMA, 4 no epilogue micro-ops,
+        // 8 no fragment reads
+#define VQ_PPABL(A)                                                                                             \
+    case 200 + A: {                                                                                             \
+        constexpr int LDSB = 2 * (256 * 128 + 144 * 128) + 4 * 32 * (144 * 2 + 16) + 4 * (144 * 16 + 64 * 12) + 64; \
+        const int units = (a.M / 256) * (a.N / 144);                                                            \
+        const int grid = units < vq_num_cus() ? units : vq_num_cus();                                           \
+        const bool res = a.epilogue == VQ_EPI_GATE_RESID;                                                       \
+        auto k = a.Kp == 1152 ? (res ? gemm_i8_pingpong_kernel<VQ_EPI_GATE_RESID, false, 9, A>                  \
+                                     : gemm_i8_pingpong_kernel<VQ_EPI_NONE, false, 9, A>)                       \
+                              : (res ? gemm_i8_pingpong_kernel<VQ_EPI_GATE_RESID, false, 36, A>                 \
+                                     : gemm_i8_pingpong_kernel<VQ_EPI_NONE, false, 36, A>);                     \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);                   \
+        (void)e;                                                                                                \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), LDSB, st, a, (int*)nullptr);                               \
+        return vq_check_launch();                                                                               \
+    }
+        switch (variant) {
+            VQ_PPABL(0) VQ_PPABL(1) VQ_PPABL(4) VQ_PPABL(5) VQ_PPABL(8) VQ_PPABL(13) VQ_PPABL(2)
+            default: break;
+        }
+#undef VQ_PPABL
     }
     if (variant >= 100 && variant < 164 && w_bits > 4) {   // profiling ablations of variant 11 (wrong results)
 #define VQ_ABL(A)                                                                                               \

@@ -108,7 +108,9 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     }
     // LDS-DMA through buffer loads: SGPR resource (token or weight base), one VGPR byte offset per piece (constant over
     // k), the k offset in an SGPR - no 64-bit address arithmetic per piece and stage.  Issued through asm with
-    // M0 = LDS destination; every wait on these transfers in this kernel is an explicit s_waitcnt vmcnt.
+    // M0 = LDS destination; every wait on these transfers in this kernel is an explicit s_waitcnt vmcnt.  The hazard
+    // recognizer does not look inside inline asm: s_nop 4 covers both the M0 write and a resource SGPR that the
+    // compiler may have re-materialised with v_readlane right before the asm (VALU-written SGPR -> VMEM: 5 wait states).
     auto mk_rsrc = [&](const void* base) {
         const unsigned long ba = (unsigned long)base;
         return int4v{(int)__builtin_amdgcn_readfirstlane((unsigned)ba),
@@ -124,11 +126,11 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
                 const unsigned dst = lds0 + stage * STAGE + p * 1024;
                 if (p < XP) {
                     const int koff = kt * 128;
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_x), "s"(koff)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_x), "s"(koff)
                                  : "memory", "m0");
                 } else {
                     const int koff = kt * WROW;
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_w), "s"(koff)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[i]), "s"(rs_w), "s"(koff)
                                  : "memory", "m0");
                 }
             }

@@ -335,9 +335,12 @@ __global__ void adaln_table_kernel(const half_t* __restrict__ table, const half_
     }
 }
 
-// r[c] = RN(1 / s[c]) for the reciprocal form of the smooth-quant division (rq_div_rcp in rowquant_fast.hip), and a count
-// of the channels that break its precondition: s not a positive normal number, significand of s all ones, or the
-// reciprocal not normal.  The host passes the reciprocal to the quantizers only when the count is zero.
+// r[c] = RN(1 / s[c]) for the reciprocal form of the smooth-quant division (rq_div_rcp in vq_common.h), and a count
+// of the channels that break its precondition: s not positive, its significand all ones, or s outside [2^-62, 2^62].
+// The magnitude window is what keeps every step of the correction exact-enough for Markstein's theorem on fp16
+// dividends (|x| in [2^-24, 2^16]): the quotient q = x r stays within [2^-86, 2^78] and the correction term e r, 24
+// binades below q, stays a normal number - neither q nor the residual fma can underflow or overflow.
+// The host passes the reciprocal to the quantizers only when the count is zero.
 __global__ void smooth_reciprocal_kernel(const float* __restrict__ s, float* __restrict__ r, int n, int32_t* n_bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -346,7 +349,7 @@ __global__ void smooth_reciprocal_kernel(const float* __restrict__ s, float* __r
     r[i] = q;
     const uint32_t b = __builtin_bit_cast(uint32_t, v), e = (b >> 23) & 0xffu;
     const uint32_t qe = (__builtin_bit_cast(uint32_t, q) >> 23) & 0xffu;
-    const bool bad = (b >> 31) || e == 0 || e == 0xff || (b & 0x7fffffu) == 0x7fffffu || qe == 0 || qe == 0xff;
+    const bool bad = (b >> 31) || e < 127u - 62u || e > 127u + 62u || (b & 0x7fffffu) == 0x7fffffu || qe == 0 || qe == 0xff;
     if (bad) atomicAdd(n_bad, 1);
 }
 

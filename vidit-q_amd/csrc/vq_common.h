@@ -73,13 +73,11 @@ __device__ __forceinline__ float vq_code(float x, float delta, float zp, float q
     return fminf(fmaxf(q, 0.0f), qmax);
 }
 
-// round(x / delta) as the correctly rounded division would give it, at the cost of a multiply: the product with the
-// reciprocal differs from the exact quotient by < 1e-4 here, so only values that close to a rounding tie take the
-// division (shared by the row quantizers and the attention kernel with the fused quantizer)
 // x / s with the reciprocal r = RN(1 / s) precomputed per channel (vq_smooth_reciprocal): q = x r, e = x - q s (exact
 // through the fma), q' = q + e r is the correctly rounded quotient (Markstein's theorem) provided s is a normal number
-// whose significand is not all ones and nothing under/overflows on the way.  vq_smooth_reciprocal counts the channels
-// outside the precondition and the host then passes no reciprocal (IEEE division below, ~4x the instructions).
+// whose significand is not all ones and nothing under/overflows on the way (guaranteed for fp16 dividends by the
+// [2^-62, 2^62] window vq_smooth_reciprocal checks).  It counts the channels outside the precondition and the host then
+// passes no reciprocal (IEEE division in the kernels, ~4x the instructions).
 // The one visible difference: -0 / s comes out as +0 (e = +0 absorbs the sign); no output of a quantizer depends on it.
 __device__ __forceinline__ float rq_div_rcp(float a, float b, float rb) {
     const float q = a * rb;
@@ -87,6 +85,9 @@ __device__ __forceinline__ float rq_div_rcp(float a, float b, float rb) {
     return __builtin_fmaf(e, rb, q);
 }
 
+// round(x / delta) as the correctly rounded division would give it, at the cost of a multiply: the product with the
+// reciprocal differs from the exact quotient by < 1e-4 here, so only values that close to a rounding tie take the
+// division (shared by the row quantizers and the attention kernel with the fused quantizer)
 __device__ __forceinline__ float rq_round_div(float x, float inv, float delta) {
     const float t = x * inv;
     float r = rintf(t);

@@ -87,7 +87,9 @@ def new_status(device) -> torch.Tensor:
 # sight (one device round trip for the bad-channel count, so: in the eager warm-up pass, never under graph capture),
 # None when the reciprocal form of x / s is not guaranteed bit-exact for some channel (the kernels then divide)
 _RCP_CACHE: "dict[int, tuple]" = {}
-_RCP_CACHE_MAX = 4096
+# bumped whenever a device tensor that a captured HIP graph may reference by address is replaced (packed weights:
+# qdiff/models/quant_layer.py; reciprocal vectors: below); graph.GraphedSampler drops its graphs when it moves
+PACK_EPOCH = [0]
 
 
 def smooth_rcp(s: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -104,10 +106,13 @@ def smooth_rcp(s: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     bad = torch.zeros(1, dtype=torch.int32, device=s.device)
     check(_L().vq_smooth_reciprocal(_p(s), _p(r), s.numel(), _p(bad), _stream()), "vq_smooth_reciprocal")
     out = r if int(bad.item()) == 0 else None
-    if len(_RCP_CACHE) >= _RCP_CACHE_MAX:
-        for k in [k for k, v in _RCP_CACHE.items() if v[0]() is None] or list(_RCP_CACHE)[:_RCP_CACHE_MAX // 2]:
-            _RCP_CACHE.pop(k, None)
     import weakref
+    # entries of dead vectors go on every insert; a LIVE entry is never evicted (its reciprocal may be referenced by
+    # address from a captured graph) - only replaced when its vector was modified in place, which moves the epoch
+    for k in [k for k, v in _RCP_CACHE.items() if v[0]() is None]:
+        _RCP_CACHE.pop(k, None)
+    if ent is not None and ent[0]() is s:
+        PACK_EPOCH[0] += 1
     _RCP_CACHE[key] = (weakref.ref(s), s._version, out)
     return out
 

@@ -6,8 +6,6 @@ the flag is therefore forced off for these classes.
 """
 from __future__ import annotations
 
-import torch
-
 from .quant_layer import QuantLayer
 
 
@@ -23,8 +21,5 @@ class QuantAttnLinearImg(QuantLayer):
 
 
 class QuantCrossAttnLinearImg(QuantAttnLinearImg):
-    def _token_view(self, input: torch.Tensor) -> torch.Tensor:
-        if input.shape[0] == 1 and not self.act_quant_params.get("dynamic", False):
-            # static: n_prompt = L, BS = 1 (dit_quant_layer.py:43-46,60-63) -> same view
-            return input
-        return input
+    """dit_quant_layer.py:34-79: kv input [1, L, C]; static (n_prompt = L, BS = 1, :43-46,60-63) and dynamic
+    quantizers both see the [B, n_tok, C] view of QuantLayer._token_view, so nothing is overridden here."""

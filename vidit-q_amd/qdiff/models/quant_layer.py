@@ -29,7 +29,7 @@ from ..quantizer.dynamic_quantizer import DynamicActQuantizer
 logger = logging.getLogger(__name__)
 
 
-PACK_EPOCH = [0]   # bumped whenever any layer drops its packed weights: captured HIP graphs hold their addresses
+PACK_EPOCH = ops.PACK_EPOCH   # shared with ops.smooth_rcp: bumped whenever a tensor a captured HIP graph may hold by address is replaced
 ANY_S = object()   # marks a packed-weight entry that was packed elsewhere (matches any smoothing vector)
 
 
@@ -185,12 +185,29 @@ class QuantLayer(nn.Module):
         ent = self._packed.get(key)
         if (ent is not None and ent[1] is wq.delta and ent[2] == self.weight._version
                 and (ent[3] is s or (ent[3] is ANY_S and ent[4] == self._act_scale_version()))):
-            return ent[0]
+            if out is None:
+                return ent[0]
+            # the caller wants the packed tensors IN its own buffers (the broadcast arena of shard.py): a valid
+            # cached entry is copied there and the entry re-pointed at the copies, never returned untouched
+            # (the arena views would otherwise stay zero and be shipped as weights)
+            old_t = ent[0].tensors()
+            if all(o.data_ptr() == t.data_ptr() for o, t in zip(out, old_t)):
+                return ent[0]
+            for o, t in zip(out, old_t):
+                if tuple(o.shape) != tuple(t.shape) or o.dtype != t.dtype:
+                    raise ValueError("packed_weight(out=): buffers do not match the packed layout")
+                o.copy_(t)
+            pw = ops.PackedWeight(out[0], out[1], out[2], out[3], ent[0].N, ent[0].K, ent[0].Kp, ent[0].n_bits)
+            self._packed[key] = (pw,) + tuple(ent[1:])
+            PACK_EPOCH[0] += 1          # captured graphs hold the old buffers' addresses
+            return pw
         W = self.weight.detach()
         if W.dtype != torch.float16:
             W = W.half()
         pw = ops.pack_weight(W.contiguous(), wq.delta.reshape(-1).float(), wq.zero_point.reshape(-1).float(),
                              wq.n_bits, s=None if s is None else s.reshape(-1).float().contiguous(), out=out)
+        if ent is not None:
+            PACK_EPOCH[0] += 1          # the replaced buffers may be referenced by captured HIP graphs (graph.py)
         self._packed[key] = (pw, wq.delta, self.weight._version, s, self._act_scale_version())
         return pw
 
