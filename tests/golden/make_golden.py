@@ -686,6 +686,181 @@ def tiny_pixart_w4a8():
     npz("tiny_pixart_w4a8.npz", **out)
 
 
+# ----------------------------------------------------------------------------- 6. depth, 6-bit plans, XL width
+def tiny_stdit_depth6(R):
+    """Error growth with DEPTH, on the reference itself: a depth-6 tiny STDiT (W8A8 dynamic, cfg_split), every block
+    output in the reference's fp32 mode and in its fp16 mode.  The full-depth GPU parity test compares the HIP path's
+    growth over 28 full-size blocks against this fp16-mode-vs-fp32 yardstick at equal depth."""
+    out = {}
+    torch.manual_seed(50)
+    cfg = dict(TINY, depth=6)
+    m = R.STDiT(enable_flashattn=False, **cfg)
+    g = torch.Generator().manual_seed(51)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.abs().sum() == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        for p in m.parameters():
+            p.copy_(h(p))
+        for n, b in m.named_buffers():
+            b.copy_(h(b))
+    m.eval()
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.clone()
+    x, y, mask = tiny_inputs(1, seed=52)
+    t = torch.tensor([640])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    with torch.no_grad():
+        qnn = wrap(R, m, 8)
+        qnn.set_quant_state(True, False)
+        qnn(x, t, y[:1], mask=mask)
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_init_done("activation")
+        qnn.set_quant_state(True, True)
+        qnn.cfg_split = True
+        for tag, q, yy in (("", qnn, y[:1]), ("_ref_fp16", _half_copy(qnn), y[:1].half())):
+            blocks = []
+            hooks = [b.register_forward_hook(lambda mod, i, o: blocks.append(o.clone())) for b in q.model.blocks]
+            out["w8a8_cond" + tag] = q(x, t, yy, mask=mask).float()
+            for hk in hooks:
+                hk.remove()
+            for i, b in enumerate(blocks):
+                out["w8a8_block%d%s" % (i, tag)] = b.float()
+    npz("tiny_stdit_depth6.npz", **out)
+
+
+def six_bit_models(R):
+    """The 6-bit plans at model level: the README's W6A6 STDiT plan (w6a6_naive_cb.yaml:16,24: 6-bit per-channel
+    weights, 6-bit dynamic per-token activations, cfg_split False -> one B = 2 forward with shared scales) and the
+    PixArt-Sigma file that is NAMED w4a8 but says n_bits: 6 (t2i/configs/quant/sigma/w4a8.yaml:30: 6-bit weights,
+    8-bit dynamic activations, quantized final layer)."""
+    out = {}
+    m = build_tiny(R, seed=60)
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.clone()
+    x, y, mask = tiny_inputs(1, seed=61)
+    t = torch.tensor([333])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    with torch.no_grad():
+        wq = ref_import.wq_cfg(6, mixed_precision=[4, 6, 8])
+        aq = ref_import.aq_cfg(n_bits=6, T=4, S=16, n_prompt=12)
+        qnn = R.QuantModel(m, wq, aq)
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.fp_layer_list = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+        qnn.set_quant_state(True, False)
+        qnn(x, t, y[:1], mask=mask)
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_init_done("activation")
+        qnn.set_quant_state(True, True)
+        qnn.cfg_split = False
+        xx, tt = torch.cat([x, x]), torch.cat([t, t])
+        out["w6a6_joint"] = qnn(xx, tt, y, mask=mask)
+        out["w6a6_cond_b1"] = qnn(x, t, y[:1], mask=mask)
+        q16 = _half_copy(qnn)
+        out["w6a6_joint_ref_fp16"] = q16(xx, tt, y.half(), mask=mask).float()
+        out["w6a6_cond_b1_ref_fp16"] = q16(x, t, y[:1].half(), mask=mask).float()
+        del q16
+        _qp(out, "qp", qnn)
+    npz("tiny_stdit_w6a6.npz", **out)
+
+    Rt = ref_import.load_t2i()
+    out = {}
+    m, g = _tiny_pixart_net(Rt.PixArtMS, 63)
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.clone()
+    x = h(torch.randn(2, 4, 16, 16, generator=g))
+    y = h(torch.randn(2, 1, 12, 32, generator=g) * 0.5)
+    mask = torch.zeros(2, 12, dtype=torch.int64)
+    mask[0, :10] = 1
+    mask[1, :6] = 1
+    t = torch.tensor([450, 450])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    with torch.no_grad():
+        qnn = _pixart_ptq(Rt, m, ref_import.wq_cfg(6, mixed_precision=[4, 6, 8]),
+                          ref_import.aq_cfg(T=1, S=64, n_prompt=12), x, t, y, mask)
+        out["w6a8"] = qnn(x, t, y, mask=mask)
+        out["w6a8_b1"] = qnn(x[:1], t[:1], y[:1], mask=mask[:1])
+        q16 = _half_copy(qnn)
+        out["w6a8_ref_fp16"] = q16(x, t, y.half(), mask=mask).float()
+        out["w6a8_b1_ref_fp16"] = q16(x[:1], t[:1], y[:1].half(), mask=mask[:1]).float()
+        del q16
+        _qp(out, "qp", qnn)
+    npz("tiny_pixart_w6a8.npz", **out)
+
+
+XL_SEED = 2024
+
+
+def xl_width(R):
+    """Reference-generated vectors at FULL WIDTH (C = 1152, 16 heads of 72, mlp 4608) and 64 tokens: one STDiT block
+    (T = 4, S = 16) and one PixArt-MS block (N = 64, B = 2), each from the imported reference in fp32 mode and in its
+    fp16 mode, W8A8 dynamic and W4A8 (4-bit weights, no channel balancing).  Weights come from a seed
+    (tests/helpers.py::seeded_state_dict) and are NOT stored: the file holds seed, inputs and the reference's outputs.
+    This pins full-width parity on the reference itself, not only through the oracle."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict
+    out = {"seed": np.array(XL_SEED)}
+    cfg = dict(input_size=(4, 8, 8), depth=1, hidden_size=1152, num_heads=16, model_max_length=12, caption_channels=64)
+    m = R.STDiT(enable_flashattn=False, **cfg)
+    m.load_state_dict(seeded_state_dict(m, XL_SEED), strict=True)
+    m.eval()
+    g = torch.Generator().manual_seed(XL_SEED + 1)
+    x = h(torch.randn(1, 4, 4, 8, 8, generator=g))
+    y = h(torch.randn(2, 1, 12, 64, generator=g) * 0.5)
+    mask = torch.zeros(1, 12, dtype=torch.int64)
+    mask[0, :9] = 1
+    t = torch.tensor([577])
+    out["stdit_x"], out["stdit_y"], out["stdit_mask"], out["stdit_t"] = x, y, mask, t
+    out["stdit_pos_embed"], out["stdit_pos_embed_temporal"] = m.pos_embed.clone(), m.pos_embed_temporal.clone()
+    import copy
+    with torch.no_grad():
+        for w_bits in (8, 4):
+            wq = ref_import.wq_cfg(w_bits, mixed_precision=[4, 6, 8])
+            aq = ref_import.aq_cfg(T=4, S=16, n_prompt=12)
+            qnn = R.QuantModel(copy.deepcopy(m), wq, aq)
+            qnn.set_module_name_for_quantizer(qnn.model)
+            qnn.fp_layer_list = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+            qnn.set_quant_state(True, False)
+            qnn(x, t, y[:1], mask=mask)
+            qnn.set_quant_init_done("weight")
+            qnn.set_quant_init_done("activation")
+            qnn.set_quant_state(True, True)
+            qnn.cfg_split = True
+            for tag, q, yy in (("", qnn, y[:1]), ("_ref_fp16", _half_copy(qnn), y[:1].half())):
+                blocks = []
+                hk = q.model.blocks[0].register_forward_hook(lambda mod, i, o: blocks.append(o.clone()))
+                o = q(x, t, yy, mask=mask).float()
+                hk.remove()
+                out["stdit_w%da8_block0%s" % (w_bits, tag)] = blocks[0].float()
+                out["stdit_w%da8_out%s" % (w_bits, tag)] = o
+    Rt = ref_import.load_t2i()
+    mp = Rt.PixArtMS(input_size=16, depth=1, hidden_size=1152, num_heads=16, model_max_length=12, caption_channels=64)
+    mp.load_state_dict(seeded_state_dict(mp, XL_SEED + 7), strict=True)
+    mp.eval()
+    g = torch.Generator().manual_seed(XL_SEED + 8)
+    x = h(torch.randn(2, 4, 16, 16, generator=g))
+    y = h(torch.randn(2, 1, 12, 64, generator=g) * 0.5)
+    mask = torch.zeros(2, 12, dtype=torch.int64)
+    mask[0, :12] = 1
+    mask[1, :7] = 1
+    t = torch.tensor([420, 420])
+    out["pixart_x"], out["pixart_y"], out["pixart_mask"], out["pixart_t"] = x, y, mask, t
+    from diffusion.model.nets.PixArt import get_2d_sincos_pos_embed
+    out["pixart_pos_embed"] = torch.from_numpy(get_2d_sincos_pos_embed(1152, (8, 8), pe_interpolation=1.0, base_size=8)).float()[None]
+    with torch.no_grad():
+        for w_bits in (8, 4):
+            qnn = _pixart_ptq(Rt, copy.deepcopy(mp), ref_import.wq_cfg(w_bits, mixed_precision=[4, 6, 8]),
+                              ref_import.aq_cfg(T=1, S=64, n_prompt=12), x, t, y, mask)
+            for tag, q, yy in (("", qnn, y), ("_ref_fp16", _half_copy(qnn), y.half())):
+                blocks = []
+                hk = q.model.blocks[0].register_forward_hook(lambda mod, i, o: blocks.append(o.clone()))
+                o = q(x, t, yy, mask=mask).float()
+                hk.remove()
+                out["pixart_w%da8_block0%s" % (w_bits, tag)] = blocks[0].float()
+                out["pixart_w%da8_out%s" % (w_bits, tag)] = o
+    npz("xl_width_ref.npz", **out)
+
+
 def main():
     assert ref_import.available(), "needs /root/reference"
     torch.set_grad_enabled(False)
@@ -700,6 +875,12 @@ def main():
             tiny_stdit(R)
         if want("static"):
             tiny_stdit_static(R)
+        if want("depth6"):
+            tiny_stdit_depth6(R)
+        if want("six_bit"):
+            six_bit_models(R)
+        if want("xl_width"):
+            xl_width(R)
     if "--stdit-only" not in sys.argv:
         if want("pixart"):
             tiny_pixart()

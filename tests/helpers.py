@@ -64,3 +64,34 @@ def tiny_inputs(n=1, seed=5):
     for i, L in enumerate([7, 12, 3][:n]):
         mask[i, :L] = 1
     return x, y, mask
+
+
+def seeded_state_dict(model: "torch.nn.Module", seed: int):
+    """Deterministic fp16-representable parameters for ``model`` from a seed alone: the golden files of the XL-width
+    vectors (tests/golden/xl_width_ref.npz) store seed + inputs + the reference's outputs instead of 30 M weights.
+    Every parameter is drawn from its OWN generator (seed + crc32 of its name), so the result depends on names and
+    shapes only - the imported reference (tests/golden/make_golden.py) and the model under test, whose state dicts
+    share both, get bit-identical weights.  The sin-cos position tables (buffers named *pos_embed*) are deterministic
+    functions of the geometry and are only rounded to fp16-representable values.  torch's CPU generator is reproducible across machines for one torch build
+    (the container and the GPU box run the same image)."""
+    import zlib
+    sd = {}
+    params = dict(model.named_parameters())
+    for name, ref in model.state_dict().items():
+        if ref.is_floating_point() and (name in params or "pos_embed" not in name):
+            # (parameters, and randomly initialised buffers such as y_embedder.y_embedding)
+            g = torch.Generator().manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
+            shape = tuple(ref.shape)
+            if name.endswith("scale_shift_table"):
+                std = 1.0 / shape[-1] ** 0.5
+            elif len(shape) >= 2:
+                fan_out, fan_in = shape[0], int(np.prod(shape[1:]))
+                std = (2.0 / (fan_in + fan_out)) ** 0.5
+            else:
+                std = 0.02
+            sd[name] = (torch.randn(shape, generator=g) * std).half().float()
+        elif ref.is_floating_point():
+            sd[name] = ref.detach().float().half().float()
+        else:
+            sd[name] = ref.detach().clone()
+    return sd

@@ -764,8 +764,9 @@ def test_gemm_pingpong_is_bit_identical_to_the_ring_kernel(ops, dev, variant, w_
     computes - same integer arithmetic, same dequantisation, same rounding.  Shapes: one unit per workgroup (no
     second group), two units (one hand-over), odd unit counts per XCD, more units than CUs x 2 (the persistent walk),
     both k extents."""
-    qa, pw, b, resid, gate = _pp_problem(ops, dev, M, N, K, w_bits)
-    kw = _pp_kwargs(ops, epi, resid, gate, M)
+    B = 2 if M % 512 == 0 else 1                       # a gate row per 256-row tile: rows_per_gate % 256 == 0
+    qa, pw, b, resid, gate = _pp_problem(ops, dev, M, N, K, w_bits, B=B)
+    kw = _pp_kwargs(ops, epi, resid, gate, M, B=B)
     ref = ops.gemm_i8(qa, pw, bias=b, variant=11, **kw)
     for rep in range(3):                               # repeated launches: the unit counters must come back to zero
         out = ops.gemm_i8(qa, pw, bias=b, variant=variant, **kw)
