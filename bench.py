@@ -9,6 +9,10 @@ cfg_split as in w8a8_dynamic.yaml) + the fused CFG/DDIM update; inputs (latent, 
 int8 weights) are resident in HBM when the timed region starts.  Multi-GPU: prompts are sharded
 over ranks (weak scaling, one prompt in flight per GPU as the reference's batch_size=1), packed
 weights are broadcast once from rank 0, no collective inside a step.
+
+Besides the headline (`value`: BASELINE.json's metric, W8A8) the line carries, at N = 1, `extras`: short legs of the
+other single-GPU configurations of BASELINE.json on the same build - W4A8 timestep-aware, W4A8 mixed precision
+(20-step schedule) and PixArt-Sigma 1024^2 W4A8 - each with its own steps/s and GEMM fraction (`--no-extras` skips them).
 """
 import argparse
 import json
@@ -23,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_INT8 = 5.03e15      # dense int8 MFMA ops/s, 256 CU x 2.4 GHz x 8192 op/clk/CU (MI355X_MICROARCH.md / datasheet)
 PEAK_HBM = 8.0e12
+GEMM_KERNEL = ("gemm_i8_wide_kernel<256,288,4,2,EPI,stagger> (W8A8 Linear: int8 MFMA 16x16x64, full-line LDS-DMA double "
+               "buffer, fused dequant epilogue)")
 
 
 def parse():
@@ -37,6 +43,7 @@ def parse():
                          "config on the 20-step schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the W4A8 / W4A8-MP / PixArt-Sigma legs")
     ap.add_argument("--gemm-variant", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region (no HIP graph)")
     ap.add_argument("--one-stream", action="store_true", help="cond and uncond serialised on one stream")
@@ -82,36 +89,62 @@ def cpu_baseline(depth_total=28):
                       "best of 2 = %.2f s; extrapolated x28 blocks x2 forward-samples per step" % tb}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    import viditq_amd  # noqa: F401
+def gemm_traffic():
+    """HBM / fabric bytes per GEMM launch: PMC passes cannot run inside this process (rocprofv3 wraps the process);
+    the committed measurement of the W8A8 command on the shipping kernels at depth 28 (tools/measure_r03.sh ->
+    profiles/r0N_gemm_traffic.json) is reported - and REFUSED (traffic null + a reason) when any GEMM source is newer
+    than the measurement, so a kernel change can never ship stale bytes."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_gemm_traffic.json")))
+    if not cands:
+        return None, "no profiles/r0N_gemm_traffic.json"
+    tj = cands[-1]
+    with open(tj) as f:
+        t_ = json.load(f)
+    want = t_.get("gemm_sources_sha256")
+    if want is not None:
+        import hashlib
+        h = hashlib.sha256()
+        for fn in sorted(glob.glob(os.path.join(ROOT, "vidit-q_amd", "csrc", "gemm_*"))):
+            if fn.endswith((".h", ".hip")):
+                with open(fn, "rb") as f:
+                    h.update(f.read())
+        if h.hexdigest() != want:
+            return None, "%s was measured on other GEMM sources (sha mismatch): re-run tools/measure_r03.sh" % os.path.basename(tj)
+    return t_["hbm_bytes_per_launch"], t_["source"]
+
+
+def gemm_roofline(timing, el, with_traffic):
+    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)
+    tot_ops = sum(o for _, _, o, _ in timing)
+    ach = tot_ops / (tot_ms * 1e-3)
+    traffic, traffic_src = gemm_traffic() if with_traffic else (None, "not measured for this plan")
+    return {"bound": "mfma", "kernel": GEMM_KERNEL,
+            "achieved": ach / 1e12, "peak": PEAK_INT8 / 1e12, "unit": "TFLOP/s", "frac": ach / PEAK_INT8,
+            "traffic": traffic, "traffic_source": traffic_src, "launches": len(timing), "avg_launch_us": tot_ms * 1e3 / len(timing),
+            "gemm_time_share_of_step": (tot_ms * 1e-3 / el) if el else None,
+            "measured": "HIP events around every GEMM launch, eager re-run of the same K steps after the timed region",
+            "algorithmic_bytes_per_launch_avg": sum(b for _, _, _, b in timing) / len(timing)}
+
+
+def stdit_leg(a, dev, rank, world, plan, steps, warmup, dist=None, events=True, hoisted=True):
+    """One STDiT-XL/2 16x512x512 measurement: build + quantize (+ broadcast), capture, W warm-up steps, K timed steps,
+    then (events) the same K steps eagerly with an event pair around every GEMM launch."""
     from viditq_amd import graph, ops, synth, shard
     from viditq_amd.config import loads_yaml
     from viditq_amd.t2v import IDDPM
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    cfg = loads_yaml(synth.W8A8_DYNAMIC if a.plan == "w8a8" else synth.W4A8_TIMESTEP_AWARE)
+    cfg = loads_yaml(synth.W8A8_DYNAMIC if plan == "w8a8" else synth.W4A8_TIMESTEP_AWARE)
+    res = {}
     with torch.no_grad():
         model = synth.build_stdit(dev, depth=a.depth)
         qnn = shard.quantize_and_distribute(model, cfg, rank, world)     # rank 0 calibrates + packs, RCCL broadcast
-        if a.gemm_variant is not None:
-            ops.DEFAULT_GEMM_VARIANT = a.gemm_variant
+        res["broadcast"] = getattr(qnn, "_broadcast_stats", None)
+        res["released_fp16_bytes"] = getattr(qnn, "_released_bytes", 0)
         assert all(b.fused_ok() for b in qnn.model.blocks), "hot path must be the fused HIP route"
-        n_sampling = 20 if a.plan == "w4a8_mp" else 100
+        n_sampling = 20 if plan == "w4a8_mp" else 100
         sch = IDDPM(num_sampling_steps=n_sampling, cfg_scale=4.0)
         mp = None
-        if a.plan == "w4a8_mp":
+        if plan == "w4a8_mp":
             from viditq_amd import ptq
             from viditq_amd.t2v.iddpm import TimestepMP
             ptq.enable_timestep_wise_mp(qnn, *synth.synthetic_mp_config(qnn, n_sampling))
@@ -149,14 +182,14 @@ def main():
         elif gs is not None and synth.uses_smooth_quant(cfg):   # one graph per smooth-quant time-range
             for t_probe in (999, 0):
                 gs.forward_pair(x, t_probe, None)
-        for j in range(a.warmup):
+        for j in range(warmup):
             x, buf = step(j, x, buf)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for j in range(a.warmup, a.warmup + a.steps):
+        for j in range(warmup, warmup + steps):
             x, buf = step(j, x, buf)
         torch.cuda.synchronize()
         if dist is not None:
@@ -166,62 +199,144 @@ def main():
         assert torch.isfinite(x).all()
         # live roofline: the SAME K steps once more, launched eagerly with a HIP-event pair around
         # every GEMM launch on the launch stream (events cannot be recorded inside a captured graph)
-        timing = None if a.no_roofline_events else []
+        timing = [] if events else None
         if timing is not None:
             ops.GEMM_TIMING = timing
-            for j in range(a.warmup, a.warmup + a.steps):
+            for j in range(warmup, warmup + steps):
                 # park the GPU for ~60 ms first so the host runs AHEAD of it: every event pair then brackets
                 # kernel execution only, not the idle gap of an eager, host-bound launch
                 torch.cuda._sleep(int(0.06 * 2.1e9))
                 x, buf = step(j, x, buf, eager=True)
             torch.cuda.synchronize()
             ops.GEMM_TIMING = None
-        status = qnn.check_status()
+        res["status"] = qnn.check_status()
         # extra (NOT the reported value): the same K steps with the step-invariant prompt work hoisted out of the loop
         # (y_embedder + every block's cross-attention K/V computed once per prompt; bit-identical outputs)
         cached = None
-        if gs is not None and hasattr(qnn.model, "set_prompt_cache"):
+        if hoisted and gs is not None and hasattr(qnn.model, "set_prompt_cache"):
             qnn.model.set_prompt_cache(True)
             gs2 = graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
             gs_keep, gs = gs, gs2
-            for j in range(a.warmup):
+            for j in range(warmup):
                 x, buf = step(j, x, buf)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for j in range(a.warmup, a.warmup + a.steps):
+            for j in range(warmup, warmup + steps):
                 x, buf = step(j, x, buf)
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t1
-            cached = {"value_this_rank": a.steps / el2, "ms_per_step": el2 / a.steps * 1e3,
+            cached = {"value_this_rank": steps / el2, "ms_per_step": el2 / steps * 1e3,
                       "note": "prompt K/V + embedding computed once per prompt instead of once per forward; exact; not the headline"}
             gs = gs_keep
             qnn.model.set_prompt_cache(False)
+        del gs, qnn, model
+    torch.cuda.empty_cache()
+    res.update(el=el, steps=steps, n_sampling=n_sampling, cached=cached,
+               roofline=gemm_roofline(timing, el, plan == "w8a8") if timing else None)
+    return res
 
+
+def pixart_leg(dev, steps=4, w_bits=4, size=1024, Lp=300):
+    """BASELINE config 5 as a timing leg: PixArt-Sigma 1024^2 (4096 tokens, prompts of up to 300 tokens), 4-bit weights,
+    dynamic per-token 8-bit activations, DPM-Solver++ 2M, cfg 4.5, the t2i loop's ONE batched (uncond | cond) forward
+    per step (quant_txt2img.py:130-153; B = 2: token scales shared over the pair as base_quantizer.py:185 does)."""
+    from viditq_amd import ops, synth
+    from viditq_amd.config import to_config
+    from viditq_amd.qdiff.models import QuantModel
+    from viditq_amd.t2i import DPMS_sigma, PixArtMS_XL_2
+    lat = size // 8
+    with torch.no_grad():
+        torch.manual_seed(0)
+        m = PixArtMS_XL_2(input_size=lat, model_max_length=Lp, pe_interpolation=lat / 64, dtype=torch.float16)
+        synth.redraw_zero_init(m, 1)
+        m = m.half().to(dev).eval()
+        wq = to_config(dict(n_bits=w_bits, per_group="channel", channel_dim=0, scale_method="min_max", round_mode="nearest",
+                            mixed_precision=[4, 6, 8]))
+        aq = to_config(dict(n_bits=8, per_group="token", scale_method="min_max", round_mode="nearest_ste", running_stat=False,
+                            dynamic=True, sym=False, n_spatial_token=(lat // 2) ** 2, n_temporal_token=1, n_prompt=Lp,
+                            smooth_quant=dict(enable=False)))
+        qnn = QuantModel(m, wq, aq, model_type="pixart")
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.fp_layer_list = ["x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder"]
+        synth.init_weight_quantizers(qnn)
+        qnn.set_quant_state(True, True)
+        assert all(b.fused_ok() for b in qnn.model.blocks)
+        g = torch.Generator().manual_seed(1)
+        y = (torch.randn(1, 1, Lp, 4096, generator=g) * 0.1).half().to(dev)
+        null_y = (torch.randn(1, 1, Lp, 4096, generator=g) * 0.1).half().to(dev)
+        mask = torch.zeros(1, Lp, dtype=torch.int64, device=dev)
+        mask[0, :180] = 1
+        z = torch.randn(1, 4, lat, lat, generator=g).to(dev)
+        solver = DPMS_sigma(qnn.forward_with_dpmsolver, condition=y, uncondition=null_y, cfg_scale=4.5,
+                            model_kwargs=dict(data_info=None, mask=mask))
+        solver.sample(z, steps=2, order=2)                     # warm-up: packing, caches
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = solver.sample(z, steps=steps, order=2)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert torch.isfinite(out).all()
+        timing = []
+        ops.GEMM_TIMING = timing
+        torch.cuda._sleep(int(0.06 * 2.1e9))
+        solver.sample(z, steps=2, order=2)
+        torch.cuda.synchronize()
+        ops.GEMM_TIMING = None
+        status = qnn.check_status()
+        del solver, qnn, m
+    torch.cuda.empty_cache()
+    roof = gemm_roofline(timing, None, False)
+    return {"workload": "PixArt-Sigma %dx%d W%dA8: %d tokens, Lp %d (180 live), DPM-Solver++ 2M, cfg 4.5, batched uncond|cond "
+                        "forward, depth 28, eager launches" % (size, size, w_bits, (lat // 2) ** 2, Lp),
+            "value": steps / el, "unit": "sampling steps/s", "steps": steps, "ms_per_step": el / steps * 1e3,
+            "status_word": status, "gemm_frac_of_int8_peak": roof["frac"], "gemm_avg_launch_us": roof["avg_launch_us"]}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import viditq_amd  # noqa: F401
+    from viditq_amd import ops
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gemm_variant is not None:
+        ops.DEFAULT_GEMM_VARIANT = a.gemm_variant
+
+    head = stdit_leg(a, dev, rank, world, a.plan, a.steps, a.warmup, dist=dist, events=not a.no_roofline_events)
+    el = head["el"]
     el_t = torch.tensor([el], device=dev, dtype=torch.float64)
+    per_rank = [el]
     if dist is not None:
+        every = [torch.zeros_like(el_t) for _ in range(world)]
+        dist.all_gather(every, el_t)
+        per_rank = [float(t.item()) for t in every]
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
     el_max = float(el_t.item())
 
-    roof = None
-    if timing:
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)
-        tot_ops = sum(o for _, _, o, _ in timing)
-        ach = tot_ops / (tot_ms * 1e-3)
-        # HBM / fabric bytes per GEMM launch: PMC passes cannot run inside this process (rocprofv3 wraps the process);
-        # the committed measurement of THIS command on the shipping kernels at depth 28 (tools/measure_r02.sh ->
-        # profiles/r02_gemm_traffic.json, regenerated whenever a GEMM kernel changes) is reported for this plan
-        traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
-        if a.plan == "w8a8" and os.path.exists(tj):
-            with open(tj) as f:
-                t_ = json.load(f)
-            traffic, traffic_src = t_["hbm_bytes_per_launch"], t_["source"]
-        roof = {"bound": "mfma", "kernel": "gemm_i8_wide_kernel<256,288,4,2,EPI,stagger> (W8A8 Linear: int8 MFMA 16x16x64, full-line LDS-DMA double buffer, fused dequant epilogue)",
-                "achieved": ach / 1e12, "peak": PEAK_INT8 / 1e12, "unit": "TFLOP/s", "frac": ach / PEAK_INT8,
-                "traffic": traffic, "traffic_source": traffic_src, "launches": len(timing), "avg_launch_us": tot_ms * 1e3 / len(timing),
-                "gemm_time_share_of_step": tot_ms * 1e-3 / el,
-                "measured": "HIP events around every GEMM launch, eager re-run of the same K steps after the timed region",
-                "algorithmic_bytes_per_launch_avg": sum(b for _, _, _, b in timing) / len(timing)}
+    extras = None
+    if rank == 0 and world == 1 and a.plan == "w8a8" and not a.no_extras and a.depth == 28:
+        extras = {}
+        for plan in ("w4a8", "w4a8_mp"):
+            r = stdit_leg(a, dev, 0, 1, plan, 4, 2, events=not a.no_roofline_events, hoisted=False)
+            extras[plan] = {"value": r["steps"] / r["el"], "unit": "denoising steps/s", "steps": r["steps"], "warmup": 2,
+                            "ms_per_step": r["el"] / r["steps"] * 1e3, "schedule": "DDIM-%d" % r["n_sampling"],
+                            "status_word": r["status"],
+                            "gemm_frac_of_int8_peak": r["roofline"]["frac"] if r["roofline"] else None,
+                            "gemm_avg_launch_us": r["roofline"]["avg_launch_us"] if r["roofline"] else None,
+                            "gemm_time_share_of_step": r["roofline"]["gemm_time_share_of_step"] if r["roofline"] else None}
+        extras["pixart_sigma_1024_w4a8"] = pixart_leg(dev)
+        extras["note"] = ("other single-GPU configurations of BASELINE.json on the same build; synthetic calibration "
+                          "(viditq_amd.synth); NOT the headline value")
+
     if rank == 0:
         steps_total = a.steps * world
         value = steps_total / el_max
@@ -237,12 +352,17 @@ def main():
                          + " + fp16 attention/residual",
                 "data": "synthetic (random-init STDiT-XL/2 weights, N(0,1) latents, random text embeds)",
                 "config": {"workload": "OpenSORA STDiT-XL/2 16x512x512 %s (%s), 1 prompt per GPU, "
-                                       "DDIM-%d schedule, cfg 4.0, cfg_split, depth %d" % (plan_name, plan_yaml, n_sampling, a.depth),
+                                       "DDIM-%d schedule, cfg 4.0, cfg_split, depth %d" % (plan_name, plan_yaml, head["n_sampling"], a.depth),
                            "tokens": 16384, "prompts_in_flight": world, "sharding": "prompt -> rank (no in-step collective)",
-                           "status_word": status, "hip_graph": not a.no_graph, "cond_uncond_streams": 1 if (a.one_stream or a.no_graph) else 2},
-                "prompt_invariants_hoisted": cached,
+                           "status_word": head["status"], "hip_graph": not a.no_graph,
+                           "cond_uncond_streams": 1 if (a.one_stream or a.no_graph) else 2},
+                # self-diagnosis of a multi-GPU run: every rank's own rate, and what the one set-up collective moved
+                "per_rank_steps_per_s": [a.steps / t for t in per_rank],
+                "weights_broadcast": head["broadcast"],
+                "prompt_invariants_hoisted": head["cached"],
                 "whole_step_int8_frac": 43.87e12 * (a.depth / 28.0) * value / world / PEAK_INT8,
-                "roofline": roof}
+                "roofline": head["roofline"],
+                "extras": extras}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

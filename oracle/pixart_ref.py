@@ -34,7 +34,8 @@ def pixart_block(sd, i, x, y, t0, y_lens, H, spec: QSpec, t_id=0):
     return x + gate_mlp * qlinear(sd, p + ".mlp.fc2", fq.gelu_tanh(h), spec, t_id)
 
 
-def pixart_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, pos_embed: torch.Tensor, t_id=None):
+def pixart_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, pos_embed: torch.Tensor, t_id=None,
+                   return_blocks: bool = False):
     """cfg: dict(H, depth, patch, out_ch).  ``pos_embed`` [1, N, C] as the model computes it (MS) or holds it
     (alpha: sd['pos_embed']).  ``t_id``: QuantModel pushes timestep[0] to every layer (quant_model.py:347)."""
     H, depth, p_ = cfg["H"], cfg["depth"], cfg["patch"]
@@ -58,10 +59,14 @@ def pixart_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, pos_embed: 
     else:
         y_lens = [yy.shape[2]] * yy.shape[0]
         yy = yy.squeeze(1).reshape(1, -1, C)
+    blocks = []
     for i in range(depth):
         x = pixart_block(sd, i, x, yy, t0, y_lens, H, spec, t_id)
+        if return_blocks:
+            blocks.append(x.clone())
     shift, scale = (sd["final_layer.scale_shift_table"].float()[None] + t[:, None]).chunk(2, dim=1)
     xf = qlinear(sd, "final_layer.linear", fq.t2i_modulate(fq.layernorm_noaffine(x), shift, scale), spec, t_id)
     c = cfg["out_ch"]
     xf = xf.reshape(B, hh, ww, p_, p_, c)
-    return torch.einsum("nhwpqc->nchpwq", xf).reshape(B, c, hh * p_, ww * p_)
+    out = torch.einsum("nhwpqc->nchpwq", xf).reshape(B, c, hh * p_, ww * p_)
+    return (out, blocks) if return_blocks else out

@@ -95,3 +95,26 @@ def seeded_state_dict(model: "torch.nn.Module", seed: int):
         else:
             sd[name] = ref.detach().clone()
     return sd
+
+
+class spy_fused:
+    """Context manager: records a clone of the residual stream after every ``forward_fused`` call of block class
+    ``cls`` (the fused route calls that method directly, so module forward hooks do not fire)."""
+
+    def __init__(self, cls):
+        self.cls, self.blocks = cls, []
+
+    def __enter__(self):
+        self.orig = self.cls.forward_fused
+        rec, orig = self.blocks, self.orig
+
+        def spy(mod, x2, *a, **k):
+            r = orig(mod, x2, *a, **k)
+            rec.append(x2.clone())
+            return r
+        self.cls.forward_fused = spy
+        return self.blocks
+
+    def __exit__(self, *exc):
+        self.cls.forward_fused = self.orig
+        return False

@@ -360,7 +360,8 @@ def test_full_size_stdit_block_matches_oracle(dev, ops, parity, plan):
     assert qnn.check_status() == 0
 
 
-def test_full_size_pixart_block_n4096_lp300_matches_oracle(dev, ops, parity):
+@pytest.mark.parametrize("w_bits", [4, 8])
+def test_full_size_pixart_block_n4096_lp300_matches_oracle(dev, ops, parity, w_bits):
     """ONE PixArt-XL/2 block at PixArt-Sigma 1024^2 size (BASELINE config 5): 4096 image tokens, prompts of up to 300
     tokens, B = 2 (uncond | cond batched as the t2i loop does: per-token scales shared over the batch), 4-bit weights,
     dynamic 8-bit activations - fused HIP route vs the CPU oracle.  Exercises the 4096-token flash attention and the
@@ -375,7 +376,7 @@ def test_full_size_pixart_block_n4096_lp300_matches_oracle(dev, ops, parity):
                      pe_interpolation=2.0, dtype=torch.float16)
     synth.redraw_zero_init(m, 22)
     m = m.half().to(dev).eval()
-    wq, aq = _cfgs(4, T=1, S=4096, mixed_precision=[4, 6, 8])
+    wq, aq = _cfgs(w_bits, T=1, S=4096, mixed_precision=[4, 6, 8])
     qnn = QuantModel(m, wq, aq, model_type="pixart")
     qnn.set_module_name_for_quantizer(qnn.model)
     qnn.fp_layer_list = list(PIX_FP)
@@ -392,14 +393,25 @@ def test_full_size_pixart_block_n4096_lp300_matches_oracle(dev, ops, parity):
     mask[0, :300] = 1
     mask[1, :143] = 1
     t = torch.tensor([500, 500], device=dev)
-    out = qnn(x, t, y, mask=mask.to(dev)).cpu().float()
+    from helpers import spy_fused
+    with spy_fused(t2i.pixart.PixArtMSBlock) as blocks:
+        out = qnn(x, t, y, mask=mask.to(dev)).cpu().float()
+    assert len(blocks) == 1
     sd = _sd_of(m)
     pe = qnn.model._pos_embed(dev, torch.float16).cpu().float()
-    spec = sr.QSpec(w_bits=4, fp_layers=pr.T2I_FP_LAYERS)
-    ref = pr.pixart_forward(sd, dict(H=16, depth=1, patch=2, out_ch=8), x.cpu().half().float(), t.cpu(), y.cpu().float(),
-                            mask, spec, pe)
-    e = _rec(parity, "full_size/pixart_depth1_model_w4a8_n4096_lp300_b2", out, ref, tokens=4096, prompt_tokens=[300, 143])
-    assert e["vs_ref_fp32"] < 4.5e-3, e          # recorded 3.5e-3: 4-bit weights + a quantized final layer (t2i FP list)
+    spec = sr.QSpec(w_bits=w_bits, fp_layers=pr.T2I_FP_LAYERS)
+    ref, rblocks = pr.pixart_forward(sd, dict(H=16, depth=1, patch=2, out_ch=8), x.cpu().half().float(), t.cpu(),
+                                     y.cpu().float(), mask, spec, pe, return_blocks=True)
+    # the BLOCK alone (what north_star's 1e-3 is about) and the depth-1 model behind it, whose output also carries the
+    # quantized final_layer.linear of the t2i FP list; yardstick at this width: the reference's own fp16 mode is 0.9e-3
+    # (W8A8) / 1.6e-3 (W4A8) from its fp32 result after one block and 5.4e-3 / 1.2e-2 at the model output
+    # (xl_width/pixart_* in tests/golden/xl_width_ref.npz)
+    eb = _rec(parity, "full_size/pixart_block_w%da8_n4096_lp300_b2" % w_bits, blocks[0].cpu().float().reshape(2, 4096, 1152),
+              rblocks[0], tokens=4096, prompt_tokens=[300, 143])
+    e = _rec(parity, "full_size/pixart_depth1_model_w%da8_n4096_lp300_b2" % w_bits, out, ref, tokens=4096,
+             prompt_tokens=[300, 143])
+    assert eb["vs_ref_fp32"] < (1.6e-3 if w_bits == 4 else 1.0e-3), eb
+    assert e["vs_ref_fp32"] < 4.5e-3, e          # recorded 3.5e-3 (W4A8): 4-bit weights + a quantized final layer
     assert qnn.check_status() == 0
 
 

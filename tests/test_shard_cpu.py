@@ -148,6 +148,58 @@ def _worker(rank, world, port, ret, plan):
         both = [torch.zeros_like(acc) for _ in range(world)]
         dist.all_gather(both, acc)
         assert torch.equal(both[0], both[1]) and float(acc) != 0.0
+        # the set-up traffic: the arena's 32-byte header, then the arena itself; no pickled object
+        st = qnn._broadcast_stats
+        assert st["messages"] == 2 and st["pickled_objects"] == 0 and st["bytes"] == arena.numel()
+        meta2, views2 = shard.arena_views(arena)                 # the buffer describes itself
+        assert len(meta2) == len(views2) and any(k.endswith("|pw|0|%d|wq" % bits) for k in views2)
+        # ranks other than 0 hold no fp16 master copy of what they received in packed form; FP layers keep theirs
+        w_bytes = sum(l.weight.numel() * l.weight.element_size() for _, l in hot)
+        if rank == 0:
+            assert all(l.weight.numel() > 0 for _, l in hot)
+        else:
+            assert w_bytes == 0 and qnn._released_bytes > 0
+            for n, l in qnn.quant_layers():
+                if not n.startswith("blocks."):
+                    assert l.weight.numel() > 0
+            hot[0][1].invalidate_packed()                        # ... and a re-pack here is refused, not faked
+            try:
+                hot[0][1].packed_weight(0)
+                raise AssertionError("re-pack of a released weight must raise")
+            except RuntimeError as e:
+                assert "released" in str(e)
+        # prepack() FIRST, then a broadcast that packs "now" (packed=None): the cached entries must be copied into the
+        # arena, not returned untouched (an arena of zeros used to be shipped)
+        torch.manual_seed(0)
+        m2 = STDiT(dtype=torch.float16, **TINY)
+        synth.redraw_zero_init(m2, 1)
+        m2 = m2.half().eval()
+        if rank == 0:
+            q2 = synth.quantize_model(m2, cfg)
+            shard.prepack(q2)
+        else:
+            q2 = synth.wrap_model(m2, cfg)
+            if synth.uses_smooth_quant(cfg):
+                synth.set_inference_state(q2, cfg, synth.REMAIN_FP)
+            else:
+                q2.set_quant_init_done("weight")
+                q2.set_quant_init_done("activation")
+                q2.set_quant_state(True, True)
+        shard.broadcast_quant_state(q2, rank, 0)
+        acc2 = torch.zeros(1, dtype=torch.float64)
+        a2 = q2._packed_arena
+        for name, layer in sorted((n, l) for n, l in q2.quant_layers() if n.startswith("blocks.")):
+            for r in range(n_ranges):
+                layer.cur_timestep_id = 0 if r == 0 else 600
+                rr, alpha = layer._range_and_alpha()
+                pw = layer.packed_weight(rr, layer.smooth_vector(rr, alpha))
+                assert pw.wq.abs().sum() > 0 and pw.sw.abs().sum() > 0
+                for t_ in pw.tensors():
+                    assert a2.data_ptr() <= t_.data_ptr() < a2.data_ptr() + a2.numel()
+                acc2 += sum(t_.double().sum() for t_ in pw.tensors())
+        both2 = [torch.zeros_like(acc2) for _ in range(world)]
+        dist.all_gather(both2, acc2)
+        assert torch.equal(both2[0], both2[1]) and float(acc2) != 0.0
         # partition + gather: 5 prompts over 2 ranks, round robin
         n_prompts = 5
         mine = shard.prompts_of_rank(n_prompts, rank, world)

@@ -390,7 +390,11 @@ __global__ __launch_bounds__(512) void gemm_i8_pingpong_kernel(GemmArgs a, int* 
         __builtin_amdgcn_sched_barrier(0);
         if (lane == 0) {
             const int zero = 0, one = 1;
-            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "+v"(grab_v) : "v"(zero), "v"(one), "s"(sched + xcd) : "memory");
+            // s_nop 4: the pointer may have just been restored from an SGPR spill lane (v_readlane) - VALU-written SGPR
+            // -> VMEM needs 5 wait states and the hazard recognizer does not look inside inline asm (the first build of
+            // this kernel faulted at sched + a stale offset exactly there, and only in the one instantiation whose
+            // register pressure spilled the pointer)
+            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "+v"(grab_v) : "v"(zero), "v"(one), "s"(sched + xcd) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
     };

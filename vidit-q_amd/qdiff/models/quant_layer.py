@@ -145,7 +145,7 @@ class QuantLayer(nn.Module):
 
     def channel_wise_scale(self, r, alpha, input: Optional[torch.Tensor] = None) -> torch.Tensor:
         """s[1,K] fp32 = act_scale[r]^alpha / (max_rows|W|)^(1-alpha)  (quant_layer.py:116-136)."""
-        w_absmax = self.weight.detach().abs().amax(dim=0).float()
+        w_absmax = self._master_weight().abs().amax(dim=0).float()
         if self.channel_wise_scale_type == "dynamic":
             a = input.abs().amax(dim=-2).float().pow(alpha).mean(dim=0, keepdim=True)
             return a / w_absmax.pow(1 - alpha)
@@ -157,6 +157,14 @@ class QuantLayer(nn.Module):
         return aq.act_scale[r].float().pow(alpha) / w_absmax.pow(1 - alpha)
 
     # ------------------------------------------------------------------ packed weights
+    def _master_weight(self) -> torch.Tensor:
+        W = self.weight.detach()
+        if W.numel() == 0:
+            raise RuntimeError("%s: the fp16 master weight was released (shard.release_fp_weights) - this rank holds the "
+                               "packed form it received and cannot re-derive smoothing vectors or re-pack"
+                               % getattr(self, "module_name", type(self).__name__))
+        return W
+
     def invalidate_packed(self):
         self._packed = {}
         self._bias_f32 = None
@@ -201,7 +209,7 @@ class QuantLayer(nn.Module):
             self._packed[key] = (pw,) + tuple(ent[1:])
             PACK_EPOCH[0] += 1          # captured graphs hold the old buffers' addresses
             return pw
-        W = self.weight.detach()
+        W = self._master_weight()
         if W.dtype != torch.float16:
             W = W.half()
         pw = ops.pack_weight(W.contiguous(), wq.delta.reshape(-1).float(), wq.zero_point.reshape(-1).float(),

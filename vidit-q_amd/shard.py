@@ -5,7 +5,8 @@ trajectories of different prompts are independent, so the multi-GPU form is: pro
 i mod R, each rank runs the whole 100-step loop locally, and the only collectives are
   (1) ONE broadcast from rank 0 of the packed int weights + quant grids, as a single flat byte
       buffer (W8: ~0.75 GB; xGMI ring broadcast is per-link bound, one large message amortises
-      launch latency), before the loop;
+      launch latency), before the loop - preceded by a 32-byte int64 header and the layout record
+      (a few hundred KB of JSON), both plain tensor broadcasts (nothing is pickled);
   (2) an optional gather of the final latents [n,4,16,64,64] after it.
 No collective runs inside a denoising step.  Backend: ``nccl`` (= RCCL) on GPUs, ``gloo`` in the
 CPU tests of the sharding logic.
@@ -102,11 +103,41 @@ def prepack(qnn: QuantModel):
         _pack_one(layer, r, t_id)
 
 
+_MAGIC = 0x56514152454E41   # "VQARENA"
+_HDR_WORDS = 4             # int64: magic, layout version, bytes of the layout record, bytes of the whole arena
+_HDR_BYTES = 8 * _HDR_WORDS
+
+
+def _payload_base(rec_n: int) -> int:
+    return (_HDR_BYTES + rec_n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
+def _encode_meta(meta: list) -> bytes:
+    import json
+    return json.dumps(meta, separators=(",", ":")).encode()
+
+
+def _decode_meta(raw: torch.Tensor) -> list:
+    import json
+    return [(n, dt, tuple(shape), off, nb) for n, dt, shape, off, nb in json.loads(raw.cpu().numpy().tobytes().decode())]
+
+
+def arena_views(arena: torch.Tensor):
+    """(meta, {name: zero-copy view}) of a self-describing arena: [header | layout record | tensors]."""
+    hdr = arena[:_HDR_BYTES].view(torch.int64).tolist()
+    if hdr[0] != _MAGIC or hdr[1] != 1 or hdr[3] != arena.numel():
+        raise RuntimeError("not a packed-weight arena: header %r, %d bytes" % (hdr, arena.numel()))
+    meta = _decode_meta(arena[_HDR_BYTES:_HDR_BYTES + hdr[2]])
+    return meta, unpack_blob(meta, arena[_payload_base(hdr[2]):])
+
+
 def prepack_into_arena(qnn: QuantModel):
     """Like :func:`prepack`, but the packed codes and per-channel terms are written straight into ONE flat byte
     buffer - the buffer that is then broadcast as is.  Rank 0 therefore never holds a second copy of the ~0.75 GB of
-    packed weights (W8A8 STDiT-XL/2); the small state (grids, act scales) is copied behind them.  Returns
-    (meta, arena)."""
+    packed weights (W8A8 STDiT-XL/2); the small state (grids, act scales) is copied behind them.  The buffer describes
+    itself: a 32-byte int64 header (magic, version, size of the layout record, total size), the layout record (JSON:
+    name, dtype, shape, offset, bytes of every tensor; offsets relative to the aligned end of the record) and the
+    tensors - nothing else has to travel, and nothing is pickled.  Returns (meta, arena)."""
     from . import ops
     dev = next(qnn.model.parameters()).device
     jobs = _pack_jobs(qnn)
@@ -118,9 +149,13 @@ def prepack_into_arena(qnn: QuantModel):
             specs.append(("%s|pw|%d|%d|%s" % (name, r, nb, f), tuple(shape), dt))
     small = _small_state(qnn)
     specs += [(k, tuple(v.shape), v.dtype) for k, v in small]
-    meta, total = _layout([(k, torch.empty(shape, dtype=dt, device="meta")) for k, shape, dt in specs])
-    arena = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
-    views = unpack_blob(meta, arena)
+    meta, payload = _layout([(k, torch.empty(shape, dtype=dt, device="meta")) for k, shape, dt in specs])
+    rec = _encode_meta(meta)
+    base = _payload_base(len(rec))
+    arena = torch.zeros(base + max(payload, 1), dtype=torch.uint8, device=dev)
+    arena[:_HDR_BYTES] = torch.tensor([_MAGIC, 1, len(rec), arena.numel()], dtype=torch.int64).view(torch.uint8).to(dev)
+    arena[_HDR_BYTES:_HDR_BYTES + len(rec)] = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
+    views = unpack_blob(meta, arena[base:])
     for name, layer, r, t_id in jobs:
         nb = layer.weight_quantizer.n_bits
         out = [views["%s|pw|%d|%d|%s" % (name, r, nb, f)] for f in ("wq", "sw", "zw", "cs")]
@@ -151,31 +186,72 @@ def _install_quant_state(qnn: QuantModel, tensors: Dict[str, torch.Tensor]):
 
 
 def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None, packed=None):
-    """One flat-buffer broadcast of grids + packed weights from ``src`` to all ranks.  ``packed`` = the (meta, arena)
-    of :func:`prepack_into_arena` on ``src`` (packed in place, no copy); without it ``src`` packs now."""
+    """Grids + packed weights from ``src`` to all ranks: the arena's own 32-byte header first (a fixed-size int64
+    tensor - the receivers learn the size to allocate), then the arena as ONE message; the layout record sits inside
+    it (:func:`prepack_into_arena`), so no Python object is pickled and nothing else travels.  ``packed`` = the
+    (meta, arena) of :func:`prepack_into_arena` on ``src`` (packed in place, no copy); without it ``src`` packs now.
+    Returns what travelled (bytes, seconds) for the bench line."""
+    import time
     import torch.distributed as dist
     dev = next(qnn.model.parameters()).device
+    hdr = torch.zeros(_HDR_WORDS, dtype=torch.int64, device=dev)
+    arena = None
     if rank == src:
-        meta, blob = packed if packed is not None else prepack_into_arena(qnn)
-        obj = [meta, int(blob.numel())]
-    else:
-        obj = [None, None]
-    dist.broadcast_object_list(obj, src=src, group=group)
-    meta, nbytes = obj
+        _, arena = packed if packed is not None else prepack_into_arena(qnn)
+        hdr.copy_(arena[:_HDR_BYTES].view(torch.int64))
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    dist.broadcast(hdr, src=src, group=group)
+    magic, ver, rec_n, total = [int(v) for v in hdr.tolist()]
+    if magic != _MAGIC or ver != 1 or total < _payload_base(rec_n):
+        raise RuntimeError("broadcast_quant_state: bad header %r" % ((magic, ver, rec_n, total),))
     if rank != src:
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    dist.broadcast(blob, src=src, group=group)
+        arena = torch.empty(total, dtype=torch.uint8, device=dev)
+    dist.broadcast(arena, src=src, group=group)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
     if rank != src:
-        _install_quant_state(qnn, unpack_blob(meta, blob))
-    qnn._packed_arena = blob        # the views installed above / packed in place live in this buffer
-    return int(nbytes)
+        _install_quant_state(qnn, arena_views(arena)[1])
+    qnn._packed_arena = arena       # the views installed above / packed in place live in this buffer
+    stats = {"bytes": int(total), "seconds": dt, "messages": 2, "pickled_objects": 0}
+    qnn._broadcast_stats = stats
+    return stats
+
+
+def release_fp_weights(qnn: QuantModel) -> int:
+    """Free the fp16 master weight of every Linear whose packed integer form is installed for all its time-ranges
+    (ranks > 0 of a sharded job never re-quantize: the master copy would sit beside the arena for nothing - 1.4 GB at
+    STDiT-XL/2).  The smoothing vectors (they need max|W| per input channel) are derived and cached first.  Afterwards
+    a re-pack (other bit width, changed statistic) raises instead of quantizing garbage.  Returns the bytes freed."""
+    freed = 0
+    for name, layer, r, t_id in _pack_jobs(qnn):
+        saved = layer.cur_timestep_id
+        if t_id is not None:
+            layer.cur_timestep_id = t_id
+        rr, alpha = layer._range_and_alpha()
+        layer.packed_weight(rr, layer.smooth_vector(rr, alpha))    # cache hit (installed) - and s is cached now
+        layer.bias_f32()
+        layer.cur_timestep_id = saved
+    done = set()
+    for name, layer, r, _ in _pack_jobs(qnn):
+        if id(layer) in done or not layer.int_route_ok():
+            continue
+        done.add(id(layer))
+        w = layer.weight
+        freed += w.numel() * w.element_size()
+        layer.released_shape = tuple(w.shape)
+        w.data = torch.empty(0, dtype=w.dtype, device=w.device)     # keeps the Parameter object and its version counter
+    return freed
 
 
 def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.REMAIN_FP,
-                            force_collective: bool = False) -> QuantModel:
+                            force_collective: bool = False, release_fp: bool = True) -> QuantModel:
     """Every rank wraps its (identically seeded / loaded) fp16 model; rank 0 runs weight PTQ and packs;
     the result reaches the other ranks by ONE broadcast.  ``force_collective``: take the arena + broadcast route at
-    world 1 too (a one-rank process group: how the RCCL calls are exercised on a single device)."""
+    world 1 too (a one-rank process group: how the RCCL calls are exercised on a single device).  ``release_fp``: ranks
+    other than 0 drop the fp16 master weights of the Linears they received in packed form (:func:`release_fp_weights`)."""
     if world == 1 and not force_collective:
         qnn = synth.quantize_model(model, cfg, fp_layers)
         prepack(qnn)
@@ -198,6 +274,8 @@ def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.R
         qnn.set_quant_init_done("activation")
         qnn.set_quant_state(True, True)
     broadcast_quant_state(qnn, rank, 0, packed=packed)
+    if rank != 0 and release_fp:
+        qnn._released_bytes = release_fp_weights(qnn)
     return qnn
 
 
