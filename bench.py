@@ -91,7 +91,7 @@ def cpu_baseline(depth_total=28):
 
 def gemm_traffic():
     """HBM / fabric bytes per GEMM launch: PMC passes cannot run inside this process (rocprofv3 wraps the process);
-    the committed measurement of the W8A8 command on the shipping kernels at depth 28 (tools/measure_r03.sh ->
+    the committed measurement of the W8A8 command on the shipping kernels at depth 28 (tools/measure_round.sh ->
     profiles/r0N_gemm_traffic.json) is reported - and REFUSED (traffic null + a reason) when any GEMM source is newer
     than the measurement, so a kernel change can never ship stale bytes."""
     import glob
@@ -101,16 +101,15 @@ def gemm_traffic():
     tj = cands[-1]
     with open(tj) as f:
         t_ = json.load(f)
-    want = t_.get("gemm_sources_sha256")
-    if want is not None:
-        import hashlib
-        h = hashlib.sha256()
-        for fn in sorted(glob.glob(os.path.join(ROOT, "vidit-q_amd", "csrc", "gemm_*"))):
-            if fn.endswith((".h", ".hip")):
-                with open(fn, "rb") as f:
-                    h.update(f.read())
-        if h.hexdigest() != want:
-            return None, "%s was measured on other GEMM sources (sha mismatch): re-run tools/measure_r03.sh" % os.path.basename(tj)
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "vidit-q_amd", "csrc", "gemm_*"))):
+        if fn.endswith((".h", ".hip")):
+            with open(fn, "rb") as f:
+                h.update(f.read())
+    if h.hexdigest() != t_.get("gemm_sources_sha256"):
+        return None, ("STALE: %s was measured on other GEMM sources (source hash differs or is absent) - re-run "
+                      "tools/measure_round.sh" % os.path.basename(tj))
     return t_["hbm_bytes_per_launch"], t_["source"]
 
 

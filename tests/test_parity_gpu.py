@@ -415,17 +415,12 @@ def test_full_size_pixart_block_n4096_lp300_matches_oracle(dev, ops, parity, w_b
     assert qnn.check_status() == 0
 
 
-# ----------------------------------------------------------------------------- eps-fill probe at model level
-def test_kv_linear_eps_fill_is_flagged_at_model_level(dev, ops):
-    """Prompt embeddings are NOT normalised: a prompt token whose embedded row is (near-)constant makes the
-    reference set EVERY token's step of cross_attn.kv_linear to 1e-6 (base_quantizer.py:220-222) - zero points of
-    ~1e6 and saturated codes, which int32 row terms cannot even represent.  The integer route keeps per-token grids
-    instead (the one deliberate deviation) and MUST say so: status bit + warning, or an exception on request."""
-    import warnings
+# ----------------------------------------------------------------------------- eps-fill at model level
+def _eps_fill_case(dev, depth=2):
     import viditq_amd  # noqa
     from viditq_amd import synth
     from viditq_amd.config import loads_yaml
-    m = synth.build_stdit(dev, depth=1, hidden_size=64, num_heads=4, input_size=(4, 8, 8), model_max_length=12,
+    m = synth.build_stdit(dev, depth=depth, hidden_size=64, num_heads=4, input_size=(4, 8, 8), model_max_length=12,
                           caption_channels=32, seed=5)
     with torch.no_grad():
         m.y_embedder.y_proj.fc1.bias.zero_()
@@ -435,17 +430,65 @@ def test_kv_linear_eps_fill_is_flagged_at_model_level(dev, ops):
     x = torch.randn(1, 4, 4, 8, 8, generator=g).to(dev)
     y = (torch.randn(1, 1, 12, 32, generator=g) * 0.3).half().to(dev)
     mask = torch.ones(1, 12, dtype=torch.int64, device=dev)
-    qnn(x, torch.tensor([500], device=dev), y, mask=mask)
+    return m, qnn, x, y, mask
+
+
+def test_kv_linear_global_eps_fill_is_reproduced_exactly(dev, ops, parity):
+    """Prompt embeddings are NOT normalised: a prompt token whose embedded row is (near-)constant makes the reference
+    set EVERY token's quant step of cross_attn.kv_linear to 1e-6 (base_quantizer.py:219-223) - zero points of ~1e6,
+    saturated codes.  The prompt K/V are therefore computed on the integer route AND on the exact fill route
+    (vq_fakequant_act + fp16 GEMM) and selected on the device by the quantizer's status bit: with an all-zero prompt
+    token the model output equals the ORACLE's (which performs the fill), without it nothing changes bit for bit."""
+    import viditq_amd.t2v.stdit as st
+    from oracle import stdit_ref as sr
+    m, qnn, x, y, mask = _eps_fill_case(dev)
+    t = torch.tensor([500], device=dev)
+    cfgd = dict(T=4, S=16, H=4, depth=2, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(4, 8, 8))
+    sd = _sd_of(m)
+    base = qnn(x, t, y, mask=mask).clone()
+    st.EXACT_KV_EPS_FILL = False
+    try:
+        assert torch.equal(qnn(x, t, y, mask=mask), base)          # no degenerate token: the select keeps the integer result
+    finally:
+        st.EXACT_KV_EPS_FILL = True
     assert qnn.check_status() == 0
     y[0, 0, 3] = 0                                  # an all-zero prompt token -> embedded row 0 -> step 0 < 1e-6
-    out = qnn(x, torch.tensor([500], device=dev), y, mask=mask)
+    out = qnn(x, t, y, mask=mask).cpu()
     assert torch.isfinite(out).all()
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        assert qnn.check_status() & 1
-    assert any("1e-6" in str(i.message) for i in w)
-    with pytest.raises(RuntimeError):
-        qnn.check_status(raise_on_eps=True)
+    ref = sr.stdit_forward(sd, cfgd, x.cpu().half().float(), t.cpu(), y.cpu().float(), mask.cpu(), sr.QSpec(w_bits=8))
+    e = _rec(parity, "eps_fill/tiny_stdit_zero_prompt_token_exact_route", out, ref)
+    assert e["vs_ref_fp32"] < 2.5e-3, e             # the tiny models' usual fp16-storage distance, not a saturated layer
+    assert qnn.check_status() == 0                  # reproduced, not flagged
+    # and the distance the integer route alone would be at (what the flag used to warn about)
+    st.EXACT_KV_EPS_FILL = False
+    try:
+        flagged = qnn(x, t, y, mask=mask).cpu()
+    finally:
+        st.EXACT_KV_EPS_FILL = True
+    parity["eps_fill/tiny_stdit_zero_prompt_token_integer_route_only"] = {"vs_ref_fp32": rel_l2(flagged, ref)}
+
+
+def test_kv_linear_eps_fill_is_flagged_when_the_exact_route_is_off(dev, ops):
+    """With VQ_EXACT_KV_EPS_FILL=0 the integer route keeps per-token grids and MUST say so: status bit +
+    warning, or an exception on request."""
+    import warnings
+    import viditq_amd.t2v.stdit as st
+    m, qnn, x, y, mask = _eps_fill_case(dev, depth=1)
+    st.EXACT_KV_EPS_FILL = False
+    try:
+        qnn(x, torch.tensor([500], device=dev), y, mask=mask)
+        assert qnn.check_status() == 0
+        y[0, 0, 3] = 0
+        out = qnn(x, torch.tensor([500], device=dev), y, mask=mask)
+        assert torch.isfinite(out).all()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert qnn.check_status() & 1
+        assert any("1e-6" in str(i.message) for i in w)
+        with pytest.raises(RuntimeError):
+            qnn.check_status(raise_on_eps=True)
+    finally:
+        st.EXACT_KV_EPS_FILL = True
 
 
 # ----------------------------------------------------------------------------- prompt sharding: 1 rank == N ranks

@@ -1,4 +1,4 @@
-"""gpurun_out/r02 (tools/measure_r02.sh) -> profiles/r02_bench_kernel_stats.csv, r02_kernel_table.md (per-kernel achieved
+"""gpurun_out/<tag> (tools/measure_round.sh <tag>) -> profiles/<tag>_bench_kernel_stats.csv, <tag>_kernel_table.md (per-kernel achieved
 GB/s and TOP/s next to the gfx950 peaks), r02_hbm_traffic.md, r02_gemm_pmc.md, r02_gemm_traffic.json, r02_bench_line.json.
 Pure CSV processing: runs anywhere."""
 import collections
@@ -9,11 +9,24 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-T = os.path.join(ROOT, "gpurun_out", "r02")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+T = os.path.join(ROOT, "gpurun_out", TAG)
 # written next to the raw data (gpurun_out/ is what travels back from the GPU box); copy into profiles/ afterwards:
-#   cp gpurun_out/r02_summary/* profiles/
-P = os.path.join(ROOT, "gpurun_out", "r02_summary")
+#   cp gpurun_out/<tag>_summary/* profiles/
+P = os.path.join(ROOT, "gpurun_out", TAG + "_summary")
+RND = TAG[1:].lstrip("0") or "?"
+
+
+def gemm_sources_sha256():
+    """hash of every GEMM source the traffic figure was measured on: bench.py refuses the figure when it differs"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "vidit-q_amd", "csrc", "gemm_*"))):
+        if fn.endswith((".h", ".hip")):
+            with open(fn, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
 os.makedirs(P, exist_ok=True)
 PEAK_I8, PEAK_F16, PEAK_HBM = 5.03e15, 2.5e15, 8.0e12
 M = 16384
@@ -71,8 +84,8 @@ ALG = {
 }
 rows = []
 tot = sum(float(r["TotalDurationNs"]) for r in stats if "spin_kernel" not in r["Name"])
-lines = ["# Round 2 - per-kernel time and achieved rates inside the bench step (MI355X, gfx950)", "",
-         "Source: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 2` (tools/measure_r02.sh; raw:",
+lines = ["# Round %s - " % RND + "per-kernel time and achieved rates inside the bench step (MI355X, gfx950)", "",
+         "Source: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 2` (tools/measure_round.sh; raw:",
          "`profiles/%s_bench_kernel_stats.csv`).  Peaks (MI355X_MICROARCH.md): int8 MFMA 5.03 POP/s, fp16 MFMA 2.5 PFLOP/s, HBM3E 8 TB/s" % TAG,
          "(6.3 TB/s achievable).  Algorithmic bytes = operands read once + result written once.", "",
          "| kernel | launches | avg us | share of GPU time | achieved | of peak |", "|---|---|---|---|---|---|"]
@@ -96,7 +109,7 @@ open(os.path.join(P, TAG + "_kernel_table.md"), "w").write("\n".join(lines) + "\
 print("\n".join(lines[6:]))
 
 # ---- HBM / fabric traffic
-lines = ["# Round 2 - HBM / fabric traffic per launch (rocprofv3 --pmc, MI355X gfx950)", "",
+lines = ["# Round %s - " % RND + "HBM / fabric traffic per launch (rocprofv3 --pmc, MI355X gfx950)", "",
          "`rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 1 --warmup 1 --no-graph",
          "--no-roofline-events --no-cpu-baseline` (depth 28, eager launches: every dispatch carries its counters; one counter per pass).",
          "Units / corrections as MI355X_MICROARCH.md prescribes: KB; FETCH_SIZE x 2 on gfx950 (calibrated here: `copy_` of 151.0 MB reads",
@@ -116,14 +129,14 @@ for k in sorted(F, key=lambda k: -sum(F[k]["FETCH_SIZE"])):
         tot_b += len(f) * (rb + wb)
 if tot_c:
     lines += ["", "GEMM launches: %d, launch-weighted mean traffic %.1f MB per launch (`roofline.traffic` of the bench line)." % (tot_c, tot_b / tot_c)]
-    json.dump({"gemm_launches": tot_c, "hbm_bytes_per_launch": tot_b / tot_c * 1e6,
+    json.dump({"gemm_launches": tot_c, "hbm_bytes_per_launch": tot_b / tot_c * 1e6, "gemm_sources_sha256": gemm_sources_sha256(),
                "source": "profiles/%s_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py at depth 28 on the shipping kernels, 2 x FETCH_SIZE correction)" % TAG},
               open(os.path.join(P, TAG + "_gemm_traffic.json"), "w"))
 open(os.path.join(P, TAG + "_hbm_traffic.md"), "w").write("\n".join(lines) + "\n")
 
 # ---- SQ / GRBM counters of the GEMM kernels
 S1, S2, G = counters("SQ1"), counters("SQ2"), counters("GRBM")
-lines = ["# Round 2 - PMC counters of the SHIPPING GEMM kernels inside the bench (gemm_i8_wide_kernel<256,288,4,2,EPI>)", "",
+lines = ["# Round %s - " % RND + "PMC counters of the SHIPPING GEMM kernels inside the bench (gemm_i8_wide_kernel<256,288,4,2,EPI>)", "",
          "`rocprofv3 --pmc <one set per pass> --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-graph ...` (depth 28).  SQ counters",
          "are summed over all waves of a dispatch; SQ_*_CYCLES in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles; 16 per",
          "`mfma_i32_16x16x64_i8`, summed over SIMDs).  GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (8 x the kernel's cycles:",

@@ -36,14 +36,25 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every kernel source to objects (in parallel) and link the shared library."""
+LAST_BUILD = {"compiled": 0, "seconds": 0.0, "lib": None}
+
+
+def build(force: bool = False, verbose: bool = True, out_dir: str = None) -> str:
+    """Compile every kernel source to objects (in parallel) and link the shared library.  ``out_dir``: build objects
+    and library THERE instead of in-tree (always from source) - how smoke() proves a from-source build on the GPU box
+    without touching the library the process has loaded."""
+    import time
+    lib = LIB if out_dir is None else os.path.join(out_dir, os.path.basename(LIB))
+    if out_dir is not None:
+        force = True
     if not force and not needs_build():
         return LIB
+    t0 = time.perf_counter()
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build") if out_dir is None else os.path.join(out_dir, "obj")
     os.makedirs(objdir, exist_ok=True)
     procs = []
+    n_compiled = 0
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
@@ -56,6 +67,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         cmd = [hipcc, *_flags(src), "-c", sp, "-o", obj]
         if verbose:
             print("[viditq build]", " ".join(cmd), flush=True)
+        n_compiled += 1
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     objs = []
     for src, obj, p in procs:
@@ -64,13 +76,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if p.returncode != 0:
                 raise RuntimeError("hipcc failed for %s:\n%s" % (src, out.decode(errors="replace")))
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
     if verbose:
         print("[viditq build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
-    return LIB
+    LAST_BUILD.update(compiled=n_compiled, seconds=time.perf_counter() - t0, lib=lib)
+    return lib
 
 
 if __name__ == "__main__":

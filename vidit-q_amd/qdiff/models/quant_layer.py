@@ -289,6 +289,42 @@ class QuantLayer(nn.Module):
             return None
         return ops.gelu_rowquant(h3, n_bits=self.act_quantizer.n_bits, s=s, status=self.status)
 
+    # ------------------------------------------------------------------ exact global eps-fill (prompt K/V)
+    def dequantized_weight_f16(self, r: int = 0, s: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The fake-quantized weight the reference multiplies with, as fp16 [N, K] (quant_layer.py:202-203 casts the
+        quantizer's output to the activation dtype): (code - zp) * delta on the layer's grid at the current bit width.
+        Cached beside the packed form; rebuilt from the int8 codes when the master weight was released."""
+        wq = self.weight_quantizer
+        key = ("deq", r, wq.n_bits)
+        ent = self._packed.get(key)
+        if ent is not None and ent[1] is wq.delta and ent[2] == self.weight._version and ent[3] is s:
+            return ent[0]
+        if self.weight.numel() > 0:
+            W = self.weight.detach().float()
+            if s is not None:
+                W = W * s.reshape(1, -1).float()
+            N = W.shape[0]
+            d, z = wq.delta.reshape(N, 1).float(), wq.zero_point.reshape(N, 1).float()
+            codes = torch.clamp(torch.round(W / d) + z, 0, 2 ** wq.n_bits - 1)
+            deq = ((codes - z) * d).half()
+        else:
+            pw = self.packed_weight(r, s)
+            if pw.n_bits <= 4:
+                raise RuntimeError("dequantized_weight_f16: master weight released and codes are nibble-packed")
+            deq = ((pw.wq[:, :pw.K].float() - pw.zw.reshape(-1, 1).float()) * pw.sw.reshape(-1, 1)).half()
+        self._packed[key] = (deq, wq.delta, self.weight._version, s)
+        return deq
+
+    def exact_fill_linear(self, x3: torch.Tensor, r: int = 0, s: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """This Linear as the reference's fp16 mode computes it INCLUDING the global eps fill of its dynamic per-token
+        quantizer (base_quantizer.py:219-223: one token with step < 1e-6 sets EVERY token's step to 1e-6):
+        vq_fakequant_act reproduces the fill on the device, the contraction is a plain fp16 GEMM.  For the few-row
+        inputs that are not normalised (prompt tokens into cross_attn.kv_linear); no host synchronisation."""
+        x = x3 if s is None else (x3.float() / s).to(x3.dtype)
+        xh, _, _, _ = ops.fakequant_act(x.contiguous(), n_bits=self.act_quantizer.n_bits)
+        b = self.bias
+        return F.linear(xh, self.dequantized_weight_f16(r, s), None if b is None else b.detach().half())
+
     # With weight_quant off and smooth_quant on, QuantLayer multiplies the FP weight by the smoothing vector
     # (quant_layer.py:188-189: (x/s)(W*s)^T = x W^T); the STDiT attention subclasses do NOT
     # (stdit_quant_layer.py:90,181,298: (x/s) W^T) - kept as released, see fp_weight_smoothed there.

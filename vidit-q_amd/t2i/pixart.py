@@ -166,8 +166,8 @@ class PixArtMSBlock(nn.Module):
         r, s = sv(ca.q_linear)
         q = ops.gemm_i8(ca.q_linear.quantize_input(x3, s), ca.q_linear.packed_weight(r, s), bias=ca.q_linear.bias_f32())
         r, s = sv(ca.kv_linear)
-        kv = ops.gemm_i8(ca.kv_linear.quantize_input(y2.view(1, -1, C), s), ca.kv_linear.packed_weight(r, s),
-                         bias=ca.kv_linear.bias_f32())
+        from ..t2v.stdit import prompt_kv_exact_fill
+        kv = prompt_kv_exact_fill(ca.kv_linear, y2.view(1, -1, C), r, s, ca.kv_linear.packed_weight(r, s))
         att_o = ca.core.cross(q, kv, kv_off, B, N, out=att_o)
         r, s = sv(ca.proj)
         ops.gemm_i8(ca.proj.quantize_input(att_o.view(B, N, C), s), ca.proj.packed_weight(r, s),

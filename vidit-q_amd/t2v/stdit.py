@@ -284,6 +284,27 @@ _ATTN_QUANT = __import__("os").environ.get("VQ_ATTN_QUANT", "1") != "0"   # atte
 _GELU_QUANT = bool(__import__('os').environ.get('VQ_GELU_QUANT'))
 
 
+# The one activation of the block that no LayerNorm precedes is the prompt (cross_attn.kv_linear): a (near-)constant
+# prompt token there triggers the reference's GLOBAL eps fill (base_quantizer.py:219-223), which the integer route does
+# not express.  With this on (default) the prompt K/V of a forward are computed both ways - integer route and
+# QuantLayer.exact_fill_linear (<= 300 rows: ~20 us per forward) - and a device-side select on the quantizer's status
+# bit keeps the integer result unless the fill fired: outputs then equal the reference's, nothing synchronises.
+EXACT_KV_EPS_FILL = __import__("os").environ.get("VQ_EXACT_KV_EPS_FILL", "1") != "0"
+
+
+def prompt_kv_exact_fill(layer, y3, r, sv, pw):
+    """kv_linear on prompt tokens y3 [1, L, C]: integer route, replaced on the device by the exact eps-fill result when
+    the quantizer flagged a token with step < 1e-6."""
+    aq = layer.act_quantizer
+    if not (EXACT_KV_EPS_FILL and isinstance(aq, DynamicActQuantizer)):
+        return ops.gemm_i8(layer.quantize_input(y3, sv), pw, bias=layer.bias_f32())
+    st = ops.new_status(y3.device)
+    qa = ops.rowquant(y3, n_bits=aq.n_bits, s=sv, status=st)
+    kv = ops.gemm_i8(qa, pw, bias=layer.bias_f32())
+    ex = layer.exact_fill_linear(y3, r, sv).reshape(kv.shape)
+    return torch.where((st & 1).bool(), ex, kv)
+
+
 class STDiTBlock(nn.Module):
     def __init__(self, hidden_size, num_heads, d_s=None, d_t=None, mlp_ratio=4.0, **unused):
         super().__init__()
@@ -404,8 +425,7 @@ class STDiTBlock(nn.Module):
         kkey = (y2, pw_kv.wq, ca.kv_linear.act_quantizer.n_bits)
         kv = self._kv_cache.get(kkey) if self.cache_prompt else None
         if kv is None:
-            ya = ca.kv_linear.quantize_input(y2.view(1, -1, C), sv)
-            kv = ops.gemm_i8(ya, pw_kv, bias=ca.kv_linear.bias_f32())
+            kv = prompt_kv_exact_fill(ca.kv_linear, y2.view(1, -1, C), r, sv, pw_kv)
             if self.cache_prompt:
                 self._kv_cache.put(kkey, kv)
         return kv
@@ -643,9 +663,26 @@ class STDiT(nn.Module):
         st = self._kv_stack
         if st is None or st[0] != key:
             stack = ops.stack_packed(pws, [l.bias_f32() for l in layers])
-            st = self._kv_stack = (key, stack, pws)      # pws kept alive: their addresses identify the stack
-        qa = l0.quantize_input(y2.view(1, -1, self.hidden_size), None)
+            st = self._kv_stack = (key, stack, pws, None)      # pws kept alive: their addresses identify the stack
+        y3 = y2.view(1, -1, self.hidden_size)
+        if not EXACT_KV_EPS_FILL:
+            out = ops.gemm_i8_batched(l0.quantize_input(y3, None), st[1])
+            return [out[i] for i in range(len(layers))]
+        # integer route for all blocks at once + the exact eps-fill route (one exact fake-quant of the shared input, one
+        # batched fp16 GEMM on the stacked dequantized weights), selected on the device by the quantizer's status bit
+        flag = ops.new_status(y2.device)
+        qa = ops.rowquant(y3, n_bits=l0.act_quantizer.n_bits, status=flag)
         out = ops.gemm_i8_batched(qa, st[1])
+        if len(st) < 4 or st[3] is None:
+            wdq = torch.stack([l.dequantized_weight_f16(0, None) for l in layers])             # [nb, 2C, K] fp16
+            bdq = torch.stack([l.bias.detach().half() for l in layers])[:, None] if l0.bias is not None else None
+            st = self._kv_stack = (st[0], st[1], st[2], (wdq, bdq))
+        wdq, bdq = st[3]
+        xh, _, _, _ = ops.fakequant_act(y3.contiguous(), n_bits=l0.act_quantizer.n_bits)
+        ex = torch.matmul(xh, wdq.transpose(1, 2))
+        if bdq is not None:
+            ex = ex + bdq
+        out = torch.where((flag & 1).bool(), ex, out)
         return [out[i] for i in range(len(layers))]
 
     def _prompt_tokens(self, y, mask, C):
