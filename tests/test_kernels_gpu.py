@@ -735,86 +735,3 @@ def test_gemm_interior_epilogue_is_bit_identical_to_general_path(ops, dev, epi, 
     assert torch.equal(fast, slow)
     assert torch.all(wide[:, N:] == 0)
 
-
-# ----------------------------------------------------------------------------- ping-pong GEMM (variants 30 / 31)
-def _pp_problem(ops, dev, M, N, K, w_bits, B=2, seed=0):
-    x = h16(B, M // B, K, scale=1.5, seed=seed + 3)
-    W = h16(N, K, scale=0.04, seed=seed + 4)
-    b = h16(N, scale=0.1, seed=seed + 5).float().to(dev)
-    qa = ops.rowquant(x.to(dev))
-    d, z = ops.weight_minmax(W.to(dev), w_bits)
-    pw = ops.pack_weight(W.to(dev), d, z, w_bits)
-    resid = h16(M, N, scale=1.0, seed=seed + 6).to(dev)
-    gate = h16(B, N, scale=0.5, seed=seed + 7).float().to(dev)
-    return qa, pw, b, resid, gate
-
-
-def _pp_kwargs(ops, epi, resid, gate, M, B=2):
-    return {"none": dict(), "gelu": dict(epilogue=ops.EPI_GELU), "resid": dict(epilogue=ops.EPI_RESID, resid=resid),
-            "gate": dict(epilogue=ops.EPI_GATE_RESID, resid=resid, gate=gate, rows_per_gate=M // B)}[epi]
-
-
-@pytest.mark.parametrize("variant", [30, 31])
-@pytest.mark.parametrize("w_bits", [8, 4])
-@pytest.mark.parametrize("epi", ["none", "gelu", "resid", "gate"])
-@pytest.mark.parametrize("M,N,K", [(512, 1152, 1152), (2048, 3456, 1152), (1024, 1152, 4608), (256, 144, 1152),
-                                   (768, 432, 4608), (4096, 4608, 1152)])
-def test_gemm_pingpong_is_bit_identical_to_the_ring_kernel(ops, dev, variant, w_bits, epi, M, N, K):
-    """Variant 30 / 31 (tile-level ping-pong, gemm_pp.h: dynamic / static unit walk) computes exactly what variant 11
-    computes - same integer arithmetic, same dequantisation, same rounding.  Shapes: one unit per workgroup (no
-    second group), two units (one hand-over), odd unit counts per XCD, more units than CUs x 2 (the persistent walk),
-    both k extents."""
-    B = 2 if M % 512 == 0 else 1                       # a gate row per 256-row tile: rows_per_gate % 256 == 0
-    qa, pw, b, resid, gate = _pp_problem(ops, dev, M, N, K, w_bits, B=B)
-    kw = _pp_kwargs(ops, epi, resid, gate, M, B=B)
-    ref = ops.gemm_i8(qa, pw, bias=b, variant=11, **kw)
-    for rep in range(3):                               # repeated launches: the unit counters must come back to zero
-        out = ops.gemm_i8(qa, pw, bias=b, variant=variant, **kw)
-        assert torch.equal(out, ref), "launch %d" % rep
-
-
-def test_gemm_pingpong_full_size_in_place_residual(ops, dev):
-    """The block's own call pattern at full size: out aliases resid (x updated in place), 16384 rows, every Linear
-    shape of the STDiT block; compared with variant 11 on a copy."""
-    for (N, K, epi) in [(1152, 1152, "gate"), (3456, 1152, "none"), (4608, 1152, "gelu"), (1152, 4608, "gate"),
-                        (1152, 1152, "resid")]:
-        M = 16384
-        qa, pw, b, resid, gate = _pp_problem(ops, dev, M, N, K, 8, B=1, seed=11)
-        kw = _pp_kwargs(ops, epi, resid, gate, M, B=1)
-        ref = ops.gemm_i8(qa, pw, bias=b, variant=11, **kw)
-        if epi in ("gate", "resid"):
-            x2 = resid.clone()
-            kw2 = dict(kw, resid=x2)
-            out = ops.gemm_i8(qa, pw, bias=b, variant=30, out=x2, **kw2)
-        else:
-            out = ops.gemm_i8(qa, pw, bias=b, variant=30, **kw)
-        assert torch.equal(out, ref), (N, K, epi)
-
-
-def test_gemm_pingpong_two_streams_share_nothing(ops, dev):
-    """Two launches in flight on two streams (the cond / uncond branches of a step) draw their units from separate
-    counter blocks: both results exact, and again after the streams have swapped problems."""
-    M = 4096
-    pa = _pp_problem(ops, dev, M, 3456, 1152, 8, seed=1)
-    pb = _pp_problem(ops, dev, M, 1152, 4608, 8, seed=2)
-    ra = ops.gemm_i8(pa[0], pa[1], bias=pa[2], variant=11)
-    rb = ops.gemm_i8(pb[0], pb[1], bias=pb[2], variant=11, epilogue=ops.EPI_RESID, resid=pb[3])
-    torch.cuda.synchronize()
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    for rep in range(4):
-        sa, sb = (s1, s2) if rep % 2 == 0 else (s2, s1)
-        with torch.cuda.stream(sa):
-            oa = [ops.gemm_i8(pa[0], pa[1], bias=pa[2], variant=30) for _ in range(3)]
-        with torch.cuda.stream(sb):
-            ob = [ops.gemm_i8(pb[0], pb[1], bias=pb[2], variant=30, epilogue=ops.EPI_RESID, resid=pb[3]) for _ in range(3)]
-        torch.cuda.synchronize()
-        assert all(torch.equal(o, ra) for o in oa) and all(torch.equal(o, rb) for o in ob), rep
-
-
-def test_gemm_pingpong_rejects_what_it_does_not_cover(ops, dev):
-    """Ragged shapes are not the ping-pong kernel's: pinned explicitly it reports VQ_ESHAPE (the default dispatch
-    sends them to the ring kernel)."""
-    qa, pw, b, _, _ = _pp_problem(ops, dev, 300, 292, 128, 8)
-    from viditq_amd._lib import VQError
-    with pytest.raises(VQError):
-        ops.gemm_i8(qa, pw, bias=b, variant=30)

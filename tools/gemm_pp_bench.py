@@ -1,8 +1,9 @@
-"""Ping-pong GEMM (variant 30 / 31, csrc/gemm_pp.h) against the ring kernel (variant 11) on the launches of one STDiT
-block-sample (16384 tokens), back to back (100 launches after a 30-launch warm-up), plus the profiling ablations of
-the ping-pong kernel from tools/lab (static unit walk): 200 = the kernel itself, 204 no epilogue micro-ops, 201 no
-LDS-DMA after the prologue, 205 neither, 208 no fragment reads, 213 MFMA + barriers only, 202 no MFMA.  GPU box only.
-  python tools/gemm_pp_bench.py [--w4] [--no-abl] [--m=16384]"""
+"""Round-3 experiment: the tile-level ping-pong GEMM (tools/lab/gemm_pp.h; lab variants 230 = units drawn from counters,
+231 = static unit walk) against the product ring kernel (variant 11) on the launches of one STDiT block-sample (16384
+tokens), back to back (100 launches after a 30-launch warm-up), plus its profiling ablations (static walk): 200 = the
+kernel itself, 201 no LDS-DMA after the prologue, 208 no fragment reads, 202 no MFMA (204 / 205 / 213 drop the epilogue
+micro-ops: the compiler then removes the dead MFMAs too, so they time the DMA stream + barriers only).  GPU box only.
+  python tools/gemm_pp_bench.py [--no-abl] [--m=16384]"""
 import os
 import sys
 
@@ -36,12 +37,10 @@ def timed(fn, n=100, warm=30):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
-lab = None
-if "--no-abl" not in sys.argv and w_bits == 8:
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
-    import lab as lab_mod
-    lab = lab_mod
-tot = {11: 0.0, 30: 0.0, 31: 0.0}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
+import lab as lab  # noqa: E402
+abl = "--no-abl" not in sys.argv and w_bits == 8
+tot = {11: 0.0, 230: 0.0, 231: 0.0}
 tot_op = 0.0
 for N, K, epi, name, count in SHAPES:
     x = (torch.randn(1, M, K, generator=g) * 1.5).half().to(dev)
@@ -59,17 +58,18 @@ for N, K, epi, name, count in SHAPES:
     gop = 2.0 * M * N * K
     tot_op += gop * count
     line = "%-11s N %4d K %4d:" % (name, N, K)
-    for v in (11, 30, 31):
-        t = timed(lambda: ops.gemm_i8(qa, pw, out=out, variant=v, **kw))
+    for v in (11, 230, 231):
+        fn = ops.gemm_i8 if v == 11 else lab.gemm_i8
+        t = timed(lambda: fn(qa, pw, out=out, variant=v, **kw))
         tot[v] += t * count
         line += "  v%d %6.1f us %.2f POPS" % (v, t * 1e6, gop / t / 1e15)
     print(line, flush=True)
-    if lab is not None and epi in (ops.EPI_NONE, ops.EPI_GATE_RESID):
+    if abl and epi in (ops.EPI_NONE, ops.EPI_GATE_RESID):
         line = "            ablations (us):"
         for v in (200, 204, 201, 205, 208, 213, 202):
             t = timed(lambda: lab.gemm_i8(qa, pw, out=out, variant=v, **kw), n=40, warm=10)
             line += "  %d: %6.1f" % (v, t * 1e6)
         print(line, flush=True)
-for v in (11, 30, 31):
+for v in (11, 230, 231):
     print("block-sample GEMM total, variant %d: %.1f us  %.2f POPS = %.1f %% of 5.03" %
           (v, tot[v] * 1e6, tot_op / tot[v] / 1e15, tot_op / tot[v] / 5.03e13))

@@ -6,7 +6,7 @@
 //   20/21 half-CU workgroups                       100+  ablations / cycle stamps of the shipping kernel (variant 11)
 // What each one taught is in DESIGN.md (5).  The shipping kernels live in vidit-q_amd/csrc/gemm_i8.hip.
 #include "../../vidit-q_amd/csrc/gemm_wide.h"
-#include "../../vidit-q_amd/csrc/gemm_pp.h"
+#include "gemm_pp.h"
 #include "gemm_half.h"
 
 int g_vq_last_hip_error = 0;
@@ -1416,6 +1416,20 @@ extern "C" int vq_lab_gemm_i8(const int8_t* xq, const float* sx, const int32_t* 
             return launch_gemm_wide<256, 288, 4, 2, false>(a, st);
         default:
             break;
+    }
+    if (variant == 230 && gemm_pp_covers(a)) {   // ping-pong kernel with units drawn from per-XCD counters (one block: one stream at a time)
+        static int* sched = [] {
+            int* p = nullptr;
+            if (hipMalloc(&p, sizeof(PPSchedBlock)) != hipSuccess) return (int*)nullptr;
+            (void)hipMemset(p, 0, sizeof(PPSchedBlock));
+            return p;
+        }();
+        if (w_bits <= 4) return launch_gemm_pingpong<true>(a, sched, vq_num_cus(), st);
+        return launch_gemm_pingpong<false>(a, sched, vq_num_cus(), st);
+    }
+    if (variant == 231 && gemm_pp_covers(a)) {   // the same with the static unit walk
+        if (w_bits <= 4) return launch_gemm_pingpong<true>(a, nullptr, vq_num_cus(), st);
+        return launch_gemm_pingpong<false>(a, nullptr, vq_num_cus(), st);
     }
     if (variant >= 200 && variant < 216 && w_bits > 4 && gemm_pp_covers(a)) {
         // profiling ablations of the product ping-pong kernel (csrc/gemm_pp.h; static unit walk; results wrong

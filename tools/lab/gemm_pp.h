@@ -1,5 +1,13 @@
-// gemm_pp.h - tile-level ping-pong int8 GEMM for gfx950 (variant 30): the epilogue of one half tile runs UNDER the
-// MFMA loop of the next one, inside one persistent 8-wave workgroup.
+// gemm_pp.h - tile-level ping-pong int8 GEMM for gfx950 (round-3 EXPERIMENT, lab variants 200+ / 230; not part of the
+// product library): the epilogue of one half tile runs UNDER the MFMA loop of the next one, inside one persistent 8-wave
+// workgroup.  Built, bit-identical to the ring kernel on every configuration it completed, and SLOWER: 536 us (static
+// unit walk) / 573 us (counter-drawn units) against 494 us for the thirteen GEMMs of a block-sample, 20.8 against 24.8
+// steps/s inside bench.py.  Why, from its own ablations: the half tiles move 1.5 x the L2 -> LDS bytes per
+// MAC, and that stream ALONE takes 67 us for the qkv launch (1.4 GB at ~21 TB/s: the aggregate L2 -> LDS rate of the
+// chip); the MFMA role beside an epilogue-role partner plus a workgroup barrier per stage takes another 67 us; the two
+// overlap to 83 us - what the ring kernel needs with everything serialised.  A test sweep also hung in one
+// configuration that was not isolated (the sweep timed out under its own limit), so this file is kept as measurement
+// equipment only.
 //
 // Why: in the full-line ring kernel (gemm_wide.h) a 256 x 288 tile with K = 1152 spends 60 % of its
 // 44 k cycles in the MFMA loop and 40 % in a cold prologue, the dequantisation (VALU) and the store drain, and nothing
@@ -25,13 +33,12 @@
 //     results are bit-identical to variant 11.
 //   * persistent grid (one workgroup per CU), work distributed per XCD: the first unit of a workgroup is static
 //     (blockIdx), later ones come from a per-XCD atomic counter, so a workgroup that starts late (CUs held by the
-//     other stream's kernels) simply takes fewer units.  The counters live in a 64-byte block per stream (host side,
-//     gemm_i8.hip) and are zeroed again by the last workgroup to finish.
+//     other stream's kernels) simply takes fewer units.  The counters live in a 64-byte block per stream (host side) and are zeroed again by the last workgroup to finish.
 // Shapes: M % 256 == 0, N % 144 == 0, Kp = 1152 or 4608 (the epilogue schedule is unrolled per k extent), no ragged
-// edge; the host falls back to variant 11 otherwise.
+// edge.
 #pragma once
 #include <utility>
-#include "gemm_common.h"
+#include "../../vidit-q_amd/csrc/gemm_common.h"
 
 struct PPSchedBlock {
     int cnt[8];       // per-XCD: units handed out beyond the static first ones

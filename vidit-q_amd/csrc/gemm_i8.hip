@@ -25,61 +25,6 @@
 // Roofline: MFMA-bound (int8 dense peak 5.03 POPS); algorithmic bytes M*K + N*K(/2) + 2*M*N (+2*M*N
 // when a residual is read).
 #include "gemm_wide.h"
-#include "gemm_pp.h"
-#include <mutex>
-
-// ---- host side of the ping-pong kernel (gemm_pp.h): CU count and the per-stream unit counters -------------------
-static int vq_num_cus() {
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
-        return v;
-    }();
-    return n;
-}
-
-// One 64-byte counter block (PPSchedBlock) per HIP stream: launches of one stream are ordered, so the block a launch
-// leaves zeroed is what the next one finds; launches on different streams may overlap and must not share counters.
-// The pool is ONE allocation made on the first eager call (never under stream capture: the capture streams of
-// graph.py are warmed up eagerly first); a stream seen for the first time only takes the next free block.  When no
-// block can be had (pool not yet allocated while capturing, or more than VQ_PP_STREAMS streams) nullptr is returned
-// and the kernel walks its units statically - still correct, only without the late-starter balancing.
-#define VQ_PP_STREAMS 64
-// VQ_GEMM_DEFAULT picks the ping-pong kernel for the shapes it covers when this is non-zero; the environment variable
-// VQ_GEMM_PP (0 / 1, read once) overrides the built-in choice for A/B runs of one binary.
-#define VQ_GEMM_DEFAULT_IS_PP_BUILTIN 0
-static bool vq_gemm_default_is_pp() {
-    static const bool on = [] {
-        const char* e = getenv("VQ_GEMM_PP");
-        return e && *e ? atoi(e) != 0 : VQ_GEMM_DEFAULT_IS_PP_BUILTIN != 0;
-    }();
-    return on;
-}
-static int* vq_pp_sched_block(hipStream_t st) {
-    static std::mutex mu;
-    static int* pool = nullptr;
-    static hipStream_t owner[VQ_PP_STREAMS];
-    static int n_owner = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!pool) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-        int* p = nullptr;
-        if (hipMalloc(&p, VQ_PP_STREAMS * sizeof(PPSchedBlock)) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, VQ_PP_STREAMS * sizeof(PPSchedBlock)) != hipSuccess) {
-            (void)hipFree(p);
-            return nullptr;
-        }
-        pool = p;
-    }
-    for (int i = 0; i < n_owner; ++i)
-        if (owner[i] == st) return pool + i * (int)(sizeof(PPSchedBlock) / sizeof(int));
-    if (n_owner == VQ_PP_STREAMS) return nullptr;
-    owner[n_owner] = st;
-    return pool + (n_owner++) * (int)(sizeof(PPSchedBlock) / sizeof(int));
-}
-
 extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R, const void* wq,
                           const float* sw, const int32_t* zw, const int32_t* cs, const float* bias, void* out,
                           int ldo, const void* resid, const float* gate, int rows_per_gate, int M, int N, int K,
@@ -99,21 +44,7 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
                ldo, rows_per_gate > 0 ? rows_per_gate : 1, M, N, K, Kp, epilogue, 0};
     hipStream_t st = (hipStream_t)stream;
     switch (variant) {
-        case 30:  // tile-level ping-pong, units drawn from the per-stream counters (static walk when no block is free)
-        case 31:  // the same with the static unit walk (A/B of the work distribution)
-            if (!gemm_pp_covers(a)) return VQ_ESHAPE;
-            {
-                int* sched = variant == 30 ? vq_pp_sched_block(st) : nullptr;
-                if (w_bits <= 4) return launch_gemm_pingpong<true>(a, sched, vq_num_cus(), st);
-                return launch_gemm_pingpong<false>(a, sched, vq_num_cus(), st);
-            }
         case VQ_GEMM_DEFAULT:
-            if (vq_gemm_default_is_pp() && gemm_pp_covers(a)) {
-                int* sched = vq_pp_sched_block(st);
-                if (w_bits <= 4) return launch_gemm_pingpong<true>(a, sched, vq_num_cus(), st);
-                return launch_gemm_pingpong<false>(a, sched, vq_num_cus(), st);
-            }
-            [[fallthrough]];
         case 11:  // full-line double buffer: 128 bytes of k per row and stage, staggered DMA issue
             if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, true, true>(a, st);
             return launch_gemm_wide<256, 288, 4, 2, true>(a, st);

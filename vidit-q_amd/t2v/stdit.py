@@ -277,11 +277,13 @@ class MultiHeadCrossAttention(nn.Module):
 
 
 # --------------------------------------------------------------------------- block
-# GELU inside fc2's quantizer pass (vq_gelu_rowquant) instead of the fc1 GEMM epilogue: fc1 -22 us, quantizer +13 us
-# in isolation, but 1 % SLOWER in the two-stream step (the quantizer's extra VALU lands where the other stream's
-# HBM-bound kernels run; the epilogue's lands under them).  Off unless VQ_GELU_QUANT is set.
+# GELU inside fc2's quantizer pass (vq_gelu_rowquant: an HBM-bound kernel whose VALU is idle) instead of the fc1 GEMM
+# epilogue (22.0 M VALU instructions for 5.3 M MFMAs there, matrix pipe 31 % busy: profiles/r02_gemm_pmc.md).  It is what
+# the reference's fp16 mode computes - act() on the fp16-rounded fc1 output (quant_layer.py:211, blocks.py:27) - and
+# neutral for the step (24.81 vs 24.76 steps/s A/B on one box, round 3; round 1 measured -1 %), while the fc1 launch
+# gets ~20 % shorter.  On by default since round 3; VQ_GELU_QUANT=0 restores the GELU epilogue.
 _ATTN_QUANT = __import__("os").environ.get("VQ_ATTN_QUANT", "1") != "0"   # attention kernels that also run the next quantizer
-_GELU_QUANT = bool(__import__('os').environ.get('VQ_GELU_QUANT'))
+_GELU_QUANT = __import__('os').environ.get('VQ_GELU_QUANT', '1') != '0'
 
 
 # The one activation of the block that no LayerNorm precedes is the prompt (cross_attn.kv_linear): a (near-)constant
