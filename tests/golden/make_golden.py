@@ -861,6 +861,45 @@ def xl_width(R):
     npz("xl_width_ref.npz", **out)
 
 
+def tiny_vae_wrapper():
+    """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
+    a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
+    latent scaling, get_latent_size - on the reference's own class."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import ToyImageVAE
+    ref_import.install()
+    import importlib
+    import types
+    toy = ToyImageVAE(91)
+
+    class AutoencoderKL:
+        @staticmethod
+        def from_pretrained(path):
+            return toy
+
+    dm = types.ModuleType("diffusers.models")
+    dm.AutoencoderKL, dm.AutoencoderKLTemporalDecoder = AutoencoderKL, AutoencoderKL
+    sys.modules["diffusers.models"] = dm
+    sys.modules["diffusers"].models = dm
+    if "opensora.models.vae" not in sys.modules:
+        ns = types.ModuleType("opensora.models.vae")
+        ns.__path__ = [os.path.join(ref_import.REF_ROOT, "t2v", "opensora", "models", "vae")]
+        sys.modules["opensora.models.vae"] = ns
+    vae_mod = importlib.import_module("opensora.models.vae.vae")
+    out = {}
+    g = torch.Generator().manual_seed(92)
+    x = h(torch.randn(2, 4, 5, 6, 4, generator=g))
+    out["x"] = x
+    with torch.no_grad():
+        for mb in (None, 2, 3, 16):
+            v = vae_mod.VideoAutoencoderKL(from_pretrained="unused", micro_batch_size=mb)
+            out["decode_mb%s" % mb] = v.decode(x)
+        out["latent_size_16_512_512"] = np.array(v.get_latent_size((16, 512, 512)))
+        out["out_channels"] = np.array(v.out_channels)
+        out["patch_size"] = np.array(v.patch_size)
+    npz("tiny_vae_wrapper.npz", **out)
+
+
 def main():
     assert ref_import.available(), "needs /root/reference"
     torch.set_grad_enabled(False)
@@ -881,6 +920,8 @@ def main():
             six_bit_models(R)
         if want("xl_width"):
             xl_width(R)
+        if want("vae"):
+            tiny_vae_wrapper()
     if "--stdit-only" not in sys.argv:
         if want("pixart"):
             tiny_pixart()

@@ -118,3 +118,28 @@ class spy_fused:
     def __exit__(self, *exc):
         self.cls.forward_fused = self.orig
         return False
+
+
+class ToyImageVAE(torch.nn.Module):
+    """A deterministic stand-in for the image VAE inside the reference's VideoAutoencoderKL (diffusers' AutoencoderKL is
+    not available): one seeded conv + pixel shuffle, ``decode(z).sample`` [n, 3, 8h, 8w].  Used by
+    tests/golden/make_golden.py (inside the REFERENCE's wrapper) and by the CPU test (inside ours)."""
+
+    class _S:
+        def __init__(self, sample):
+            self.sample = sample
+
+    class _C:
+        latent_channels = 4
+
+    def __init__(self, seed=91):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.conv = torch.nn.Conv2d(4, 3 * 64, 3, padding=1)
+        with torch.no_grad():
+            self.conv.weight.copy_(torch.randn(self.conv.weight.shape, generator=g) * 0.1)
+            self.conv.bias.copy_(torch.randn(self.conv.bias.shape, generator=g) * 0.1)
+        self.config = ToyImageVAE._C()
+
+    def decode(self, z):
+        return ToyImageVAE._S(torch.nn.functional.pixel_shuffle(self.conv(z), 8))

@@ -220,3 +220,64 @@ def test_fused_qkv_checkpoint_is_split_like_the_reference(tmp_path):
     dst2 = STDiT(**kw)
     load_split_qkv(dst2, torch.load(str(path), map_location="cpu"))
     assert all(torch.equal(dst2.state_dict()[k], v) for k, v in sd.items())
+
+
+# ----------------------------------------------------------------------------- VAE decode (the step after the loop)
+def test_video_vae_wrapper_matches_the_reference_wrapper():
+    """viditq_amd.t2v.vae.VideoAutoencoderKL against outputs of the REFERENCE's wrapper class (vae.py:36-57) around the
+    same deterministic toy image VAE: frame flattening, micro-batches that do and do not divide B*T, the 0.18215 scaling,
+    get_latent_size, the attributes the inference script reads."""
+    import numpy as np
+    from helpers import ToyImageVAE, load_npz
+    import viditq_amd  # noqa
+    from viditq_amd.t2v.vae import VideoAutoencoderKL
+    g = load_npz("tiny_vae_wrapper.npz")
+    toy = ToyImageVAE(91)
+    for mb in (None, 2, 3, 16):
+        v = VideoAutoencoderKL(toy, micro_batch_size=mb)
+        out = v.decode(g["x"])
+        assert out.shape == (2, 3, 5, 48, 32)
+        assert torch.allclose(out, g["decode_mb%s" % mb], rtol=0, atol=1e-6), mb
+    assert v.get_latent_size((16, 512, 512)) == [int(a) for a in np.asarray(g["latent_size_16_512_512"])]
+    assert v.out_channels == int(g["out_channels"]) and tuple(v.patch_size) == tuple(int(a) for a in np.asarray(g["patch_size"]))
+    with pytest.raises(AssertionError):
+        v.get_latent_size((16, 500, 512))
+
+
+def test_sd_vae_decoder_shape_contract_and_checkpoint_key_mapping():
+    """The restated SD-VAE decode path (parity with diffusers unpinned: the package is absent): 8x spatial upsampling,
+    3 output channels, per-frame independence through the video wrapper, and the key layout of a diffusers
+    AutoencoderKL checkpoint (old attention names, encoder keys ignored)."""
+    import viditq_amd  # noqa
+    from viditq_amd.t2v.vae import AutoencoderKLDecoder, VideoAutoencoderKL
+    torch.manual_seed(0)
+    dec = AutoencoderKLDecoder(block_out_channels=(16, 32, 32, 32), layers_per_block=1, norm_num_groups=8).eval()
+    keys = set(dec.state_dict())
+    for k in ("post_quant_conv.weight", "decoder.conv_in.weight", "decoder.mid_block.attentions.0.to_q.weight",
+              "decoder.mid_block.attentions.0.to_out.0.bias", "decoder.mid_block.resnets.1.conv2.weight",
+              "decoder.up_blocks.0.resnets.0.norm1.weight", "decoder.up_blocks.0.upsamplers.0.conv.weight",
+              "decoder.up_blocks.3.resnets.0.conv_shortcut.weight",        # 32 -> 16 channels in this tiny config
+              "decoder.conv_norm_out.weight", "decoder.conv_out.bias"):
+        assert k in keys, k
+    assert not any(k.startswith("decoder.up_blocks.3.upsamplers") for k in keys)          # no upsampling in the last block
+    z = torch.randn(3, 4, 6, 5)
+    with torch.no_grad():
+        img = dec.decode(z).sample
+        assert img.shape == (3, 3, 48, 40)
+        v = VideoAutoencoderKL(dec, micro_batch_size=2)
+        lat = torch.randn(1, 4, 3, 6, 5)
+        vid = v.decode(lat)
+        assert vid.shape == (1, 3, 3, 48, 40)
+        one = dec.decode(lat[:, :, 1] / 0.18215).sample
+        assert torch.allclose(vid[:, :, 1], one, atol=1e-5)
+    # a pre-0.20 diffusers checkpoint: 1x1-conv attention projections named query / key / value / proj_attn + encoder keys
+    sd = {}
+    for k, t in dec.state_dict().items():
+        k2 = k.replace("to_q", "query").replace("to_k", "key").replace("to_v", "value").replace("to_out.0", "proj_attn")
+        sd[k2] = t[:, :, None, None].clone() if ("attentions" in k and t.dim() == 2) else t.clone()
+    sd["encoder.conv_in.weight"] = torch.zeros(1)
+    sd["quant_conv.weight"] = torch.zeros(1)
+    dec2 = AutoencoderKLDecoder(block_out_channels=(16, 32, 32, 32), layers_per_block=1, norm_num_groups=8).eval()
+    dec2.load_diffusers_state_dict(sd)
+    with torch.no_grad():
+        assert torch.equal(dec2.decode(z).sample, img)

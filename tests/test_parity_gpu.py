@@ -410,7 +410,7 @@ def test_full_size_pixart_block_n4096_lp300_matches_oracle(dev, ops, parity, w_b
               rblocks[0], tokens=4096, prompt_tokens=[300, 143])
     e = _rec(parity, "full_size/pixart_depth1_model_w%da8_n4096_lp300_b2" % w_bits, out, ref, tokens=4096,
              prompt_tokens=[300, 143])
-    assert eb["vs_ref_fp32"] < (1.6e-3 if w_bits == 4 else 1.0e-3), eb
+    assert eb["vs_ref_fp32"] < 6.5e-4, eb        # recorded 4.96e-4 (W4A8) / 4.98e-4 (W8A8): north_star's 1e-3 holds on the block
     assert e["vs_ref_fp32"] < 4.5e-3, e          # recorded 3.5e-3 (W4A8): 4-bit weights + a quantized final layer
     assert qnn.check_status() == 0
 

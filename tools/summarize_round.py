@@ -61,7 +61,7 @@ cal_copy_f = cal_copy_f[0] if cal_copy_f else float("nan")
 
 
 def short(k):
-    for a, b in (("gemm_i8_wide_kernel<256, 288, 4, 2, 0", "GEMM epi none (qkv x2, cross-q, kv)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 1", "GEMM fc1 + GELU"),
+    for a, b in (("gemm_i8_wide_kernel<256, 288, 4, 2, 0", "GEMM epi none (qkv x2, cross-q, fc1, kv)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 1", "GEMM fc1 + GELU epilogue"),
                  ("gemm_i8_wide_kernel<256, 288, 4, 2, 2", "GEMM + gate*y + resid (proj x2, fc2)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 3", "GEMM + resid (cross proj)"),
                  ("attn_fwd32d_kernel", "spatial attention (flash, 1024 keys)"), ("attn_fwd8_kernel", "spatial attention, previous generation"), ("attn_temporal_quant", "temporal attention + proj quantizer"),
                  ("attn_cross_reg", "cross attention (K/V^T in registers)"), ("ln_modulate_rowquant_half", "LN + modulate + quantizer C=1152"),
@@ -73,7 +73,15 @@ def short(k):
 
 # algorithmic work per launch at 16 x 512 x 512: bytes moved once, ops
 ALG = {
-    "GEMM fc1 + GELU": (M * 1152 + 4608 * 1152 + 2 * M * 4608, 2.0 * M * 4608 * 1152, "i8"),
+    "GEMM fc1 + GELU epilogue": (M * 1152 + 4608 * 1152 + 2 * M * 4608, 2.0 * M * 4608 * 1152, "i8"),
+    # launch-weighted means over the launches of one block-sample (the few batched prompt-kv launches are ignored):
+    # qkv x 2 (N 3456) + cross-q (N 1152) + fc1 (N 4608, GELU in the next quantizer since round 3), all K = 1152
+    "GEMM epi none (qkv x2, cross-q, fc1, kv)": ((2 * (M * 1152 + 3456 * 1152 + 2 * M * 3456) + (M * 1152 + 1152 * 1152 + 2 * M * 1152)
+                                                   + (M * 1152 + 4608 * 1152 + 2 * M * 4608)) / 4,
+                                                  2.0 * M * 1152 * (2 * 3456 + 1152 + 4608) / 4, "i8"),
+    # proj x 2 (N = K = 1152) + fc2 (N 1152, K 4608), each reading the residual as well
+    "GEMM + gate*y + resid (proj x2, fc2)": ((2 * (M * 1152 + 1152 * 1152 + 4 * M * 1152) + (M * 4608 + 1152 * 4608 + 4 * M * 1152)) / 3,
+                                             2.0 * M * 1152 * (2 * 1152 + 4608) / 3, "i8"),
     "GEMM + resid (cross proj)": (M * 1152 + 1152 * 1152 + 4 * M * 1152, 2.0 * M * 1152 * 1152, "i8"),
     "spatial attention (flash, 1024 keys)": (4 * 2 * M * 1152, 4.0 * 16 * 16 * 1024 * 1024 * 72, "f16"),
     "temporal attention + proj quantizer": (3 * 2 * M * 1152 + M * 1152, 4.0 * 1024 * 16 * 16 * 16 * 72, "hbm"),
@@ -108,7 +116,9 @@ for r in stats:
 open(os.path.join(P, TAG + "_kernel_table.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[6:]))
 
-# ---- HBM / fabric traffic
+# ---- HBM / fabric traffic (raw counter tables present only on the GPU box: nothing is rewritten without them)
+if not F or not W:
+    sys.exit(0)
 lines = ["# Round %s - " % RND + "HBM / fabric traffic per launch (rocprofv3 --pmc, MI355X gfx950)", "",
          "`rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py --steps 1 --warmup 1 --no-graph",
          "--no-roofline-events --no-cpu-baseline` (depth 28, eager launches: every dispatch carries its counters; one counter per pass).",
