@@ -126,112 +126,123 @@ def gemm_roofline(timing, el, with_traffic):
             "algorithmic_bytes_per_launch_avg": sum(b for _, _, _, b in timing) / len(timing)}
 
 
-def stdit_leg(a, dev, rank, world, plan, steps, warmup, dist=None, events=True, hoisted=True):
-    """One STDiT-XL/2 16x512x512 measurement: build + quantize (+ broadcast), capture, W warm-up steps, K timed steps,
-    then (events) the same K steps eagerly with an event pair around every GEMM launch."""
-    from viditq_amd import graph, ops, synth, shard
+def stdit_legs(a, dev, rank, world, plans, steps, warmup, dist=None, events=True, hoisted=True):
+    """STDiT-XL/2 16x512x512 measurements of ``plans`` on ONE model build (plans of one weight format share it: the
+    mixed-precision plan is the W4A8 model with per-layer bit widths switched per step range): build + quantize
+    (+ broadcast) once, then per plan: capture, W warm-up steps, K timed steps, and (events) the same K steps eagerly
+    with an event pair around every GEMM launch."""
+    from viditq_amd import shard, synth
     from viditq_amd.config import loads_yaml
-    from viditq_amd.t2v import IDDPM
-    cfg = loads_yaml(synth.W8A8_DYNAMIC if plan == "w8a8" else synth.W4A8_TIMESTEP_AWARE)
-    res = {}
+    cfg = loads_yaml(synth.W8A8_DYNAMIC if plans[0] == "w8a8" else synth.W4A8_TIMESTEP_AWARE)
+    out = []
     with torch.no_grad():
         model = synth.build_stdit(dev, depth=a.depth)
         qnn = shard.quantize_and_distribute(model, cfg, rank, world)     # rank 0 calibrates + packs, RCCL broadcast
-        res["broadcast"] = getattr(qnn, "_broadcast_stats", None)
-        res["released_fp16_bytes"] = getattr(qnn, "_released_bytes", 0)
         assert all(b.fused_ok() for b in qnn.model.blocks), "hot path must be the fused HIP route"
-        n_sampling = 20 if plan == "w4a8_mp" else 100
-        sch = IDDPM(num_sampling_steps=n_sampling, cfg_scale=4.0)
-        mp = None
-        if plan == "w4a8_mp":
-            from viditq_amd import ptq
-            from viditq_amd.t2v.iddpm import TimestepMP
-            ptq.enable_timestep_wise_mp(qnn, *synth.synthetic_mp_config(qnn, n_sampling))
-            mp = TimestepMP(qnn)
-        # one prompt per GPU in flight; prompt index = rank (prompt i -> rank i mod R)
-        embeds, lens = synth.synthetic_prompts(world, dev)
-        x = synth.synthetic_latent(rank, device=dev).float()
-        y = embeds["y"][rank:rank + 1]                                   # [1, 2, 1, 120, 4096]
-        y = y.permute(1, 0, 2, 3, 4).reshape(2, 1, 120, 4096)
-        mask = embeds["mask"][rank:rank + 1]
-        y_c, y_u = y[:1], y[1:]
-        idx = list(range(sch.num_timesteps))[::-1]
-        buf = torch.empty_like(x)
+        for plan in plans:
+            res = _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, events, hoisted)
+            res["broadcast"] = getattr(qnn, "_broadcast_stats", None)
+            out.append(res)
+        del qnn, model
+    torch.cuda.empty_cache()
+    return out
 
-        gs = None if a.no_graph else graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
 
-        def step(j, x, buf, eager=False):
-            i = idx[j % len(idx)]
-            t_id = sch.timestep_map[i]
-            key = mp.apply(i) if mp is not None else None   # per-layer bit widths of this step's range
-            if gs is not None and not eager:            # both forward-samples replayed from one HIP graph
-                cond, unc = gs.forward_pair(x, t_id, key)
-            else:
-                t = torch.full((1,), t_id, device=dev, dtype=torch.long)
-                cond = qnn(x, t, y_c, mask=mask, timestep_id=t_id)
-                unc = qnn(x, t, y_u, mask=mask, timestep_id=t_id)
-            out = sch.ddim_step(x, cond, unc, i, sch.cfg_scale, 0.0, out=buf)
-            return out, x
+def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, events, hoisted):
+    from viditq_amd import graph, ops, synth
+    from viditq_amd.t2v import IDDPM
+    res = {}
+    n_sampling = 20 if plan == "w4a8_mp" else 100
+    sch = IDDPM(num_sampling_steps=n_sampling, cfg_scale=4.0)
+    mp = None
+    if plan == "w4a8_mp":
+        from viditq_amd import ptq
+        from viditq_amd.t2v.iddpm import TimestepMP
+        ptq.enable_timestep_wise_mp(qnn, *synth.synthetic_mp_config(qnn, n_sampling))
+        mp = TimestepMP(qnn)
+    # one prompt per GPU in flight; prompt index = rank (prompt i -> rank i mod R)
+    embeds, lens = synth.synthetic_prompts(world, dev)
+    x = synth.synthetic_latent(rank, device=dev).float()
+    y = embeds["y"][rank:rank + 1]                                   # [1, 2, 1, 120, 4096]
+    y = y.permute(1, 0, 2, 3, 4).reshape(2, 1, 120, 4096)
+    mask = embeds["mask"][rank:rank + 1]
+    y_c, y_u = y[:1], y[1:]
+    idx = list(range(sch.num_timesteps))[::-1]
+    buf = torch.empty_like(x)
 
-        if mp is not None:                              # pack + capture every mixed-precision key up front
-            for i in idx[::max(1, len(idx) // 4)]:
-                key = mp.apply(i)
-                if gs is not None:
-                    gs.forward_pair(x, sch.timestep_map[i], key)
-        elif gs is not None and synth.uses_smooth_quant(cfg):   # one graph per smooth-quant time-range
-            for t_probe in (999, 0):
-                gs.forward_pair(x, t_probe, None)
+    gs = None if a.no_graph else graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
+
+    def step(j, x, buf, eager=False):
+        i = idx[j % len(idx)]
+        t_id = sch.timestep_map[i]
+        key = mp.apply(i) if mp is not None else None   # per-layer bit widths of this step's range
+        if gs is not None and not eager:            # both forward-samples replayed from one HIP graph
+            cond, unc = gs.forward_pair(x, t_id, key)
+        else:
+            t = torch.full((1,), t_id, device=dev, dtype=torch.long)
+            cond = qnn(x, t, y_c, mask=mask, timestep_id=t_id)
+            unc = qnn(x, t, y_u, mask=mask, timestep_id=t_id)
+        out = sch.ddim_step(x, cond, unc, i, sch.cfg_scale, 0.0, out=buf)
+        return out, x
+
+    if mp is not None:                              # pack + capture every mixed-precision key up front
+        for i in idx[::max(1, len(idx) // 4)]:
+            key = mp.apply(i)
+            if gs is not None:
+                gs.forward_pair(x, sch.timestep_map[i], key)
+    elif gs is not None and synth.uses_smooth_quant(cfg):   # one graph per smooth-quant time-range
+        for t_probe in (999, 0):
+            gs.forward_pair(x, t_probe, None)
+    for j in range(warmup):
+        x, buf = step(j, x, buf)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(warmup, warmup + steps):
+        x, buf = step(j, x, buf)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(x).all()
+    # live roofline: the SAME K steps once more, launched eagerly with a HIP-event pair around
+    # every GEMM launch on the launch stream (events cannot be recorded inside a captured graph)
+    timing = [] if events else None
+    if timing is not None:
+        ops.GEMM_TIMING = timing
+        for j in range(warmup, warmup + steps):
+            # park the GPU for ~60 ms first so the host runs AHEAD of it: every event pair then brackets
+            # kernel execution only, not the idle gap of an eager, host-bound launch
+            torch.cuda._sleep(int(0.06 * 2.1e9))
+            x, buf = step(j, x, buf, eager=True)
+        torch.cuda.synchronize()
+        ops.GEMM_TIMING = None
+    res["status"] = qnn.check_status()
+    # extra (NOT the reported value): the same K steps with the step-invariant prompt work hoisted out of the loop
+    # (y_embedder + every block's cross-attention K/V computed once per prompt; bit-identical outputs)
+    cached = None
+    if hoisted and gs is not None and hasattr(qnn.model, "set_prompt_cache"):
+        qnn.model.set_prompt_cache(True)
+        gs2 = graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
+        gs_keep, gs = gs, gs2
         for j in range(warmup):
             x, buf = step(j, x, buf)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t1 = time.perf_counter()
         for j in range(warmup, warmup + steps):
             x, buf = step(j, x, buf)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        assert torch.isfinite(x).all()
-        # live roofline: the SAME K steps once more, launched eagerly with a HIP-event pair around
-        # every GEMM launch on the launch stream (events cannot be recorded inside a captured graph)
-        timing = [] if events else None
-        if timing is not None:
-            ops.GEMM_TIMING = timing
-            for j in range(warmup, warmup + steps):
-                # park the GPU for ~60 ms first so the host runs AHEAD of it: every event pair then brackets
-                # kernel execution only, not the idle gap of an eager, host-bound launch
-                torch.cuda._sleep(int(0.06 * 2.1e9))
-                x, buf = step(j, x, buf, eager=True)
-            torch.cuda.synchronize()
-            ops.GEMM_TIMING = None
-        res["status"] = qnn.check_status()
-        # extra (NOT the reported value): the same K steps with the step-invariant prompt work hoisted out of the loop
-        # (y_embedder + every block's cross-attention K/V computed once per prompt; bit-identical outputs)
-        cached = None
-        if hoisted and gs is not None and hasattr(qnn.model, "set_prompt_cache"):
-            qnn.model.set_prompt_cache(True)
-            gs2 = graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
-            gs_keep, gs = gs, gs2
-            for j in range(warmup):
-                x, buf = step(j, x, buf)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for j in range(warmup, warmup + steps):
-                x, buf = step(j, x, buf)
-            torch.cuda.synchronize()
-            el2 = time.perf_counter() - t1
-            cached = {"value_this_rank": steps / el2, "ms_per_step": el2 / steps * 1e3,
-                      "note": "prompt K/V + embedding computed once per prompt instead of once per forward; exact; not the headline"}
-            gs = gs_keep
-            qnn.model.set_prompt_cache(False)
-        del gs, qnn, model
-    torch.cuda.empty_cache()
+        el2 = time.perf_counter() - t1
+        cached = {"value_this_rank": steps / el2, "ms_per_step": el2 / steps * 1e3,
+                  "note": "prompt K/V + embedding computed once per prompt instead of once per forward; exact; not the headline"}
+        gs = gs_keep
+        qnn.model.set_prompt_cache(False)
+    del gs
     res.update(el=el, steps=steps, n_sampling=n_sampling, cached=cached,
-               roofline=gemm_roofline(timing, el, plan == "w8a8") if timing else None)
+           roofline=gemm_roofline(timing, el, plan == "w8a8") if timing else None)
     return res
 
 
@@ -310,7 +321,7 @@ def main():
     if a.gemm_variant is not None:
         ops.DEFAULT_GEMM_VARIANT = a.gemm_variant
 
-    head = stdit_leg(a, dev, rank, world, a.plan, a.steps, a.warmup, dist=dist, events=not a.no_roofline_events)
+    head = stdit_legs(a, dev, rank, world, [a.plan], a.steps, a.warmup, dist=dist, events=not a.no_roofline_events)[0]
     el = head["el"]
     el_t = torch.tensor([el], device=dev, dtype=torch.float64)
     per_rank = [el]
@@ -324,8 +335,8 @@ def main():
     extras = None
     if rank == 0 and world == 1 and a.plan == "w8a8" and not a.no_extras and a.depth == 28:
         extras = {}
-        for plan in ("w4a8", "w4a8_mp"):
-            r = stdit_leg(a, dev, 0, 1, plan, 4, 2, events=not a.no_roofline_events, hoisted=False)
+        legs = stdit_legs(a, dev, 0, 1, ["w4a8", "w4a8_mp"], 4, 2, events=not a.no_roofline_events, hoisted=False)
+        for plan, r in zip(("w4a8", "w4a8_mp"), legs):
             extras[plan] = {"value": r["steps"] / r["el"], "unit": "denoising steps/s", "steps": r["steps"], "warmup": 2,
                             "ms_per_step": r["el"] / r["steps"] * 1e3, "schedule": "DDIM-%d" % r["n_sampling"],
                             "status_word": r["status"],
