@@ -231,8 +231,13 @@ def release_fp_weights(qnn: QuantModel) -> int:
         if t_id is not None:
             layer.cur_timestep_id = t_id
         rr, alpha = layer._range_and_alpha()
-        layer.packed_weight(rr, layer.smooth_vector(rr, alpha))    # cache hit (installed) - and s is cached now
+        sv = layer.smooth_vector(rr, alpha)
+        layer.packed_weight(rr, sv)                                # cache hit (installed) - and s is cached now
         layer.bias_f32()
+        if name.endswith("kv_linear"):
+            # the exact eps-fill route of the prompt K/V multiplies with the DEQUANTIZED weight (t2v/stdit.py): derive
+            # and cache it while the master copy (or, for int8 codes, the packed form) can still give it
+            layer.dequantized_weight_f16(rr, sv)
         layer.cur_timestep_id = saved
     done = set()
     for name, layer, r, _ in _pack_jobs(qnn):
