@@ -281,3 +281,33 @@ def test_sd_vae_decoder_shape_contract_and_checkpoint_key_mapping():
     dec2.load_diffusers_state_dict(sd)
     with torch.no_grad():
         assert torch.equal(dec2.decode(z).sample, img)
+
+
+def test_bench_refuses_stale_gemm_traffic(tmp_path, monkeypatch):
+    """bench.py reports roofline.traffic only when profiles/r0N_gemm_traffic.json carries the hash of the GEMM sources
+    it was measured on; any edit of csrc/gemm_* (or a file without a hash) yields traffic = None plus the reason."""
+    import hashlib
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t, src = bench.gemm_traffic()                       # the committed file of this round matches the committed sources
+    assert t is not None and t > 1e8, src
+    fake = tmp_path / "repo"
+    (fake / "profiles").mkdir(parents=True)
+    csrc = fake / "vidit-q_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "gemm_x.h").write_text("// v1\n")
+    h = hashlib.sha256((csrc / "gemm_x.h").read_bytes()).hexdigest()
+    (fake / "profiles" / "r09_gemm_traffic.json").write_text(json.dumps(
+        {"hbm_bytes_per_launch": 123.0, "source": "s", "gemm_sources_sha256": h}))
+    monkeypatch.setattr(bench, "ROOT", str(fake))
+    assert bench.gemm_traffic() == (123.0, "s")
+    (csrc / "gemm_x.h").write_text("// v2\n")            # a kernel edit without a new measurement
+    t, why = bench.gemm_traffic()
+    assert t is None and "STALE" in why
+    (fake / "profiles" / "r09_gemm_traffic.json").write_text(json.dumps({"hbm_bytes_per_launch": 1.0, "source": "s"}))
+    assert bench.gemm_traffic()[0] is None               # no hash recorded: refused as well
