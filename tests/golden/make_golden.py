@@ -900,6 +900,36 @@ def tiny_vae_wrapper():
     npz("tiny_vae_wrapper.npz", **out)
 
 
+ATTN_KAT_SEED = 3001
+ATTN_KAT_CASES = [("L1024", 2, 1024, 16), ("L160", 3, 160, 4), ("L16", 64, 16, 8)]   # name, sequences, length, stored-row stride
+
+
+def attention_kats(R):
+    """The reference's Attention module (blocks.py:113-195) on its NON-flash branch (:179-187: q * scale, q k^T in the
+    activation dtype, fp32 softmax, cast back, attn v) at full width - C = 1152, 16 heads of 72 - for a long (1024),
+    a medium (160) and the temporal (16) sequence length, fp32 and fp16 mode.  Weights and inputs come from seeds
+    (tests/helpers.py: seeded_state_dict / attn_kat_input); the file stores every ``stride``-th output row.  This pins
+    the attention boundary - whose production kernels (flash-attn / xformers) are absent - on the reference's own code."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import attn_kat_input, seeded_state_dict
+    att = R.blocks.Attention(1152, num_heads=16, qkv_bias=True, enable_flashattn=False)
+    att.load_state_dict(seeded_state_dict(att, ATTN_KAT_SEED), strict=True)
+    att.eval()
+    import copy
+    a16 = copy.deepcopy(att).half()
+    out = {"seed": np.array(ATTN_KAT_SEED)}
+    with torch.no_grad():
+        for name, nseq, L, stride in ATTN_KAT_CASES:
+            x = attn_kat_input(ATTN_KAT_SEED, name, nseq, L)
+            o = att(x)
+            o16 = a16(x.half()).float()
+            if name == "L16":
+                out[name], out[name + "_ref_fp16"] = o[::stride].clone(), o16[::stride].clone()
+            else:
+                out[name], out[name + "_ref_fp16"] = o[:, ::stride].clone(), o16[:, ::stride].clone()
+    npz("attention_kats.npz", **out)
+
+
 def main():
     assert ref_import.available(), "needs /root/reference"
     torch.set_grad_enabled(False)
@@ -922,6 +952,8 @@ def main():
             xl_width(R)
         if want("vae"):
             tiny_vae_wrapper()
+        if want("attn_kats"):
+            attention_kats(R)
     if "--stdit-only" not in sys.argv:
         if want("pixart"):
             tiny_pixart()

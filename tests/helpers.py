@@ -143,3 +143,11 @@ class ToyImageVAE(torch.nn.Module):
 
     def decode(self, z):
         return ToyImageVAE._S(torch.nn.functional.pixel_shuffle(self.conv(z), 8))
+
+
+def attn_kat_input(seed: int, name: str, nseq: int, L: int, C: int = 1152):
+    """Seeded fp16-representable input [nseq, L, C] of an attention KAT case (tests/golden/attention_kats.npz stores
+    seed + outputs only)."""
+    import zlib
+    g = torch.Generator().manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
+    return torch.randn(nseq, L, C, generator=g).half().float()

@@ -397,3 +397,32 @@ def test_xl_width_reference_vectors_pin_the_oracle_at_c1152():
         #  the fp32 LayerNorm / GEMM summation order show in the output: 1.1e-4 at W8, below at W4)
         assert rel_l2(out, g["pixart_w%da8_out" % w_bits]) < 3e-4, w_bits
     assert np.isfinite(float(out.abs().sum()))
+
+
+ATTN_KAT_CASES = [("L1024", 2, 1024, 16), ("L160", 3, 160, 4), ("L16", 64, 16, 8)]   # as tests/golden/make_golden.py
+
+
+def _attn_kat_module_sd(seed):
+    import torch.nn as nn
+    from helpers import seeded_state_dict
+
+    class A(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.k, self.v, self.proj = [nn.Linear(1152, 1152) for _ in range(4)]
+    return seeded_state_dict(A(), seed)
+
+
+def test_attention_kats_from_the_reference_non_flash_branch():
+    """The oracle's self-attention (FP Linears + attention_core) against the reference's Attention module on its
+    softmax branch (blocks.py:179-187) at C = 1152 / 16 heads of 72, sequence lengths 1024, 160 and 16."""
+    from helpers import attn_kat_input
+    g = load_npz("attention_kats.npz")
+    seed = int(g["seed"])
+    sd = {"a." + k: v for k, v in _attn_kat_module_sd(seed).items()}
+    spec = sr.QSpec(quant=False)
+    for name, nseq, L, stride in ATTN_KAT_CASES:
+        x = attn_kat_input(seed, name, nseq, L)
+        out = sr.self_attention(sd, "a", x, nseq, L, 16, spec, 0, nseq)
+        got = out[::stride] if name == "L16" else out[:, ::stride]
+        assert rel_l2(got, g[name]) < 1e-5, name
