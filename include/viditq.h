@@ -137,6 +137,16 @@ int vq_fakequant_act(const void* x, void* out, uint8_t* codes, float* delta_out,
                      int B, int n_tok, int C, int n_bits, int mode, float* scratch,
                      int32_t* status, void* stream);
 
+/* Global eps-fill fix-up behind the integer route of a few-row Linear whose input is not normalised (the prompt
+ * tokens into cross_attn.kv_linear).  base_quantizer.py:219-223 sets EVERY token's step to 1e-6 as soon as one token's
+ * step is below 1e-6; vq_rowquant raises VQ_ST_EPSFILL in `flag` for that case instead.  When the flag is clear the
+ * kernel returns at once; when it is set, out[g, row, :] is overwritten with the reference's fp16-mode result:
+ * (x / s rounded to fp16) -> exact quantize / dequantize on the step-1e-6 grid -> fp32 contraction with the
+ * dequantized fp16 weight wdq [n_batch, N, C] (+ bias [n_batch, N] fp16, nullable) -> fp16.
+ * x [L, C] fp16 (shared by the batch), s nullable [C] fp32, out [n_batch, L, N] fp16. */
+int vq_epsfill_fixup(const int32_t* flag, const void* x, const float* s, const void* wdq, const void* bias,
+                     void* out, int n_batch, int L, int C, int N, int n_bits, void* stream);
+
 /* ---- weight packer ---------------------------------------------------------
  * Replaces WeightQuantizer.forward on W*s (base_quantizer.py:129-144 via
  * quant_layer.py:174-185): codes = clamp(round(W*s/delta)+zp, 0, 2^b-1) on the

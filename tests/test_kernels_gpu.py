@@ -113,6 +113,37 @@ def test_fakequant_act_exact_including_eps_fill(ops, dev):
     assert torch.equal(out.cpu(), dq.half())
 
 
+@pytest.mark.parametrize("smooth", [False, True])
+def test_epsfill_fixup_against_the_oracle_fake_quant(ops, dev, smooth):
+    """vq_epsfill_fixup: flag clear -> the integer-route output stays as it is, bit for bit; flag set -> every row is the
+    reference's result with ALL tokens on the 1e-6 grid (base_quantizer.py:219-223): oracle fake-quant of x / s (the
+    degenerate token makes it fill), fp32 contraction with the dequantized weights of a batch of Linears."""
+    g = torch.Generator().manual_seed(5)
+    L, C, N, nb = 37, 1152, 520, 3
+    x = (torch.randn(L, C, generator=g) * 0.5).half()
+    x[5] = 0
+    s = (torch.rand(C, generator=g) + 0.5) if smooth else None
+    wdq = (torch.randn(nb, N, C, generator=g) * 0.05).half()
+    for bias in (None, (torch.randn(nb, N, generator=g) * 0.1).half()):
+        out0 = torch.randn(nb, L, N, generator=g).half().to(dev)
+        flag = ops.new_status(dev)
+        args = (x.to(dev), None if s is None else s.to(dev), wdq.to(dev), None if bias is None else bias.to(dev))
+        out = ops.epsfill_fixup(flag, *args, out0.clone())
+        assert torch.equal(out, out0)
+        flag.fill_(1)
+        out = ops.epsfill_fixup(flag, *args, out0.clone()).cpu().float()
+        xs = x.float() if s is None else (x.float() / s).half().float()
+        _, dq, delta, _, eps = fq.dyn_act_quant(xs[None], 8)
+        assert eps and bool((delta == 1e-6).all())
+        ref = torch.matmul(dq[0].half().double(), wdq.double().transpose(1, 2))
+        if bias is not None:
+            ref = ref + bias.double()[:, None]
+        # the filled grid saturates: x_dq ~ the row minimum everywhere, results of order 1; fp16 output rounding plus
+        # the fp32 accumulation order are what separates the two
+        assert rel_l2(out, ref) < 1e-3, rel_l2(out, ref)
+        assert float((out.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
 # ----------------------------------------------------------------------------- weights
 @pytest.mark.parametrize("n_bits", [8, 6, 4])
 @pytest.mark.parametrize("smooth", [False, True])

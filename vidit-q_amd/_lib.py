@@ -30,6 +30,7 @@ SIGNATURES = {
     "vq_rowquant_smooth_multi": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vq_smooth_div_check": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
     "vq_fakequant_act": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "vq_epsfill_fixup": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vq_pack_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vq_weight_minmax": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "vq_gemm_i8_batched": (_i, [_vp] * 10 + [_i] * 6 + [_vp]),

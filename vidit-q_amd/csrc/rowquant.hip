@@ -323,6 +323,55 @@ __global__ __launch_bounds__(256) void fq_apply_kernel(const half_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// Global eps-fill fix-up for a few-row Linear (base_quantizer.py:219-223).  The integer route quantizes every token on
+// its own grid and raises VQ_ST_EPSFILL when one token's step falls below 1e-6; the reference then sets EVERY token's
+// step to 1e-6, which no int8 grid holds (zero points of millions).  This kernel runs behind the integer route on the
+// same output: when the flag is clear - the case on every real prompt - each workgroup reads one word and returns; when
+// it is set, the output rows are recomputed as the reference's fp16 mode does: x / s rounded to fp16, exact
+// quantize -> dequantize with step 1e-6, contraction with the dequantized fp16 weight in fp32, bias, one rounding.
+// grid (ceil(N / 256), L, n_batch); dynamic LDS: C halves.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void epsfill_fixup_kernel(const int32_t* __restrict__ flag, const half_t* __restrict__ x,
+                                                            const float* __restrict__ s, const half_t* __restrict__ wdq,
+                                                            const half_t* __restrict__ bias, half_t* __restrict__ out,
+                                                            int L, int C, int N, int n_bits) {
+    if (!(*flag & VQ_ST_EPSFILL)) return;
+    extern __shared__ half_t fx_row[];
+    __shared__ float red[4];
+    const int row = blockIdx.y, g = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const half_t* xr = x + (size_t)row * C;
+    float vmin = INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float v = (float)xr[c];
+        const half_t h = s ? (half_t)__fdiv_rn(v, s[c]) : (half_t)v;
+        fx_row[c] = h;
+        vmin = fminf(vmin, (float)h);
+    }
+    vmin = wave_min_f(vmin);
+    if (lane == 0) red[wv] = vmin;
+    __syncthreads();
+    vmin = fminf(fminf(fminf(red[0], red[1]), fminf(red[2], red[3])), 0.0f);
+    const float qmax = (float)((1 << n_bits) - 1);
+    const float d = VQ_EPS, zp = rintf(__fdiv_rn(-vmin, d));
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float q = vq_code((float)fx_row[c], d, zp, qmax);
+        fx_row[c] = (half_t)((q - zp) * d);
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const half_t* wr = wdq + ((size_t)g * N + n) * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; c += 8) {
+        const half8 w8 = *reinterpret_cast<const half8*>(wr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)fx_row[c + e] * (float)w8[e];
+    }
+    if (bias) acc += (float)bias[(size_t)g * N + n];
+    out[((size_t)g * L + row) * N + n] = (half_t)acc;
+}
+
+// ---------------------------------------------------------------------------
 // AdaLN table: mod[j,b,c] = table[j,c] + t0[b, j*C + c]   (stdit.py:100-102); [J][B][C] so that
 // every chunk (shift/scale/gate) is a contiguous [B, C] fp32 matrix
 // ---------------------------------------------------------------------------
@@ -479,6 +528,17 @@ extern "C" int vq_fakequant_act(const void* x, void* out, uint8_t* codes, float*
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(fq_apply_kernel, dim3(blocks), dim3(256), 0, st, (const half_t*)x, (half_t*)out, codes, d, z,
                        np, rows, n_tok, C, n_bits);
+    return vq_check_launch();
+}
+
+extern "C" int vq_epsfill_fixup(const int32_t* flag, const void* x, const float* s, const void* wdq, const void* bias,
+                                void* out, int n_batch, int L, int C, int N, int n_bits, void* stream) {
+    if (!flag || !x || !wdq || !out || n_batch <= 0 || L <= 0 || C <= 0 || N <= 0) return VQ_EINVAL;
+    if (C % 8 != 0 || C > 32768 || L > 65535 || n_batch > 65535) return VQ_ESHAPE;
+    if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
+    hipLaunchKernelGGL(epsfill_fixup_kernel, dim3((N + 255) / 256, L, n_batch), dim3(256), (size_t)C * sizeof(half_t),
+                       (hipStream_t)stream, flag, (const half_t*)x, s, (const half_t*)wdq, (const half_t*)bias,
+                       (half_t*)out, L, C, N, n_bits);
     return vq_check_launch();
 }
 

@@ -271,6 +271,27 @@ def fakequant_act(x: torch.Tensor, n_bits: int = 8, delta: Optional[torch.Tensor
     return out, codes, d, z
 
 
+def epsfill_fixup(flag: torch.Tensor, x: torch.Tensor, s: Optional[torch.Tensor], wdq: torch.Tensor,
+                  bias: Optional[torch.Tensor], out: torch.Tensor, n_bits: int = 8) -> torch.Tensor:
+    """In-place global eps-fill fix-up of ``out`` [n_batch, L, N] fp16 = integer-route Linear(s) of the shared input x
+    [L, C] fp16: a no-op kernel while ``flag`` (the quantizer's private status word) is clear, the reference's fp16-mode
+    result with every token on the 1e-6 grid when it is set (base_quantizer.py:219-223).  wdq [n_batch, N, C] fp16
+    dequantized weights, bias [n_batch, N] fp16 or None."""
+    _req(x, torch.float16, "x"); _req(wdq, torch.float16, "wdq"); _req(out, torch.float16, "out")
+    nb, N, C = wdq.shape
+    L = x.shape[-2]
+    assert x.shape[-1] == C and x.numel() == L * C and out.numel() == nb * L * N
+    assert x.is_contiguous() and wdq.is_contiguous() and out.is_contiguous()
+    if s is not None:
+        _req(s, torch.float32, "s")
+    if bias is not None:
+        _req(bias, torch.float16, "bias")
+        assert bias.numel() == nb * N and bias.is_contiguous()
+    check(_L().vq_epsfill_fixup(_p(flag), _p(x), _p(s), _p(wdq), _p(bias), _p(out), nb, L, C, N, n_bits, _stream()),
+          "vq_epsfill_fixup")
+    return out
+
+
 # --------------------------------------------------------------------------- weights
 def weight_minmax(W: torch.Tensor, n_bits: int, s: Optional[torch.Tensor] = None, force_eps: bool = False,
                   status: Optional[torch.Tensor] = None):

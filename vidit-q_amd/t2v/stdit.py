@@ -288,9 +288,10 @@ _GELU_QUANT = __import__('os').environ.get('VQ_GELU_QUANT', '1') != '0'
 
 # The one activation of the block that no LayerNorm precedes is the prompt (cross_attn.kv_linear): a (near-)constant
 # prompt token there triggers the reference's GLOBAL eps fill (base_quantizer.py:219-223), which the integer route does
-# not express.  With this on (default) the prompt K/V of a forward are computed both ways - integer route and
-# QuantLayer.exact_fill_linear (<= 300 rows: ~20 us per forward) - and a device-side select on the quantizer's status
-# bit keeps the integer result unless the fill fired: outputs then equal the reference's, nothing synchronises.
+# not express.  With this on (default) one small kernel follows the integer route (vq_epsfill_fixup): it reads the
+# quantizer's private status word, returns at once when it is clear and otherwise overwrites the K/V rows with the
+# reference's fp16-mode result on the 1e-6 grid: outputs then equal the reference's, nothing synchronises (round 3's
+# first form - both routes computed with torch ops and a device-side select - cost PixArt-Sigma 5 % of its step).
 EXACT_KV_EPS_FILL = __import__("os").environ.get("VQ_EXACT_KV_EPS_FILL", "1") != "0"
 
 
@@ -303,8 +304,10 @@ def prompt_kv_exact_fill(layer, y3, r, sv, pw):
     st = ops.new_status(y3.device)
     qa = ops.rowquant(y3, n_bits=aq.n_bits, s=sv, status=st)
     kv = ops.gemm_i8(qa, pw, bias=layer.bias_f32())
-    ex = layer.exact_fill_linear(y3, r, sv).reshape(kv.shape)
-    return torch.where((st & 1).bool(), ex, kv)
+    b = layer.bias
+    ops.epsfill_fixup(st, y3.contiguous(), sv, layer.dequantized_weight_f16(r, sv)[None],
+                      None if b is None else b.detach().half().contiguous(), kv, n_bits=aq.n_bits)
+    return kv
 
 
 class STDiTBlock(nn.Module):
@@ -677,14 +680,10 @@ class STDiT(nn.Module):
         out = ops.gemm_i8_batched(qa, st[1])
         if len(st) < 4 or st[3] is None:
             wdq = torch.stack([l.dequantized_weight_f16(0, None) for l in layers])             # [nb, 2C, K] fp16
-            bdq = torch.stack([l.bias.detach().half() for l in layers])[:, None] if l0.bias is not None else None
+            bdq = torch.stack([l.bias.detach().half() for l in layers]).contiguous() if l0.bias is not None else None
             st = self._kv_stack = (st[0], st[1], st[2], (wdq, bdq))
         wdq, bdq = st[3]
-        xh, _, _, _ = ops.fakequant_act(y3.contiguous(), n_bits=l0.act_quantizer.n_bits)
-        ex = torch.matmul(xh, wdq.transpose(1, 2))
-        if bdq is not None:
-            ex = ex + bdq
-        out = torch.where((flag & 1).bool(), ex, out)
+        ops.epsfill_fixup(flag, y3.contiguous(), None, wdq, bdq, out, n_bits=l0.act_quantizer.n_bits)
         return [out[i] for i in range(len(layers))]
 
     def _prompt_tokens(self, y, mask, C):
