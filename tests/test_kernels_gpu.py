@@ -26,7 +26,7 @@ def h16(*shape, scale=1.0, seed=0):
 
 # GEMM kernels of the product library: -1 = the library's own choice per shape, explicit numbers pin one kernel
 # (retired generations are measured from tools/lab, not tested here)
-GEMM_VARIANTS = [-1, 11]
+GEMM_VARIANTS = [-1, 11, 16]          # library's choice, 256 x 288 tile, 128 x 288 tile
 
 
 # ----------------------------------------------------------------------------- rowquant
@@ -257,6 +257,30 @@ def test_gemm_epilogues(ops, dev):
     r2 = resid.to(dev).clone()
     ops.gemm_i8(qa, pw, bias=b.to(dev), out=r2, epilogue=ops.EPI_RESID, resid=r2)
     assert rel_l2(r2.cpu().float(), resid.float() + y) < 5e-4
+
+
+@pytest.mark.parametrize("w_bits", [8, 4])
+@pytest.mark.parametrize("M,N,K", [(8192, 1152, 1152), (1024, 1152, 4608), (300, 2304, 1152), (391, 580, 256)])
+def test_gemm_half_height_tile_is_bit_identical(ops, dev, M, N, K, w_bits):
+    """The 128 x 288 form of the ring kernel (variant 16: what the library picks when all its tiles fit one round of the
+    256 CUs - PixArt-Sigma's N = 1152 Linears at M = 8192, prompt K/V) computes every output element with the arithmetic
+    of the 256 x 288 form (variant 11): equal bit for bit, every epilogue, ragged edges, W8 and W4."""
+    B = 2 if M % 512 == 0 else 1       # gate rows aligned with both tile heights: a tile that straddles two samples
+    # takes the un-folded gate path, which rounds differently from the folded one (both inside the oracle tolerance)
+    x = h16(1, M, K, scale=1.5, seed=M + K).to(dev)
+    W = h16(N, K, scale=0.04, seed=N).to(dev)
+    b = h16(N, scale=0.1, seed=5).float().to(dev)
+    resid = h16(M, N, scale=1.0, seed=6).to(dev)
+    gate = h16(B, N, scale=0.5, seed=7).float().to(dev)
+    qa = ops.rowquant(x)
+    d, z = ops.weight_minmax(W, w_bits)
+    pw = ops.pack_weight(W, d, z, w_bits)
+    for kw in (dict(epilogue=ops.EPI_NONE), dict(epilogue=ops.EPI_GELU), dict(epilogue=ops.EPI_RESID, resid=resid),
+               dict(epilogue=ops.EPI_GATE_RESID, resid=resid, gate=gate, rows_per_gate=M // B)):
+        o11 = ops.gemm_i8(qa, pw, bias=b, variant=11, **kw)
+        o16 = ops.gemm_i8(qa, pw, bias=b, variant=16, **kw)
+        assert torch.equal(o11, o16), kw["epilogue"]
+        assert torch.equal(ops.gemm_i8(qa, pw, bias=b, **kw), o11)
 
 
 def test_gemm_full_tile_property_linearity(ops, dev):

@@ -7,24 +7,44 @@
 //   out[m,n] = sx[m]*sw[n] * (acc - zw[n]*R[m] - zx[m]*cs[n]) + bias[n],  acc = sum_k xs*ws  (int32)
 // and, by epilogue, GELU-tanh (modules.py:57) and the gate/residual adds (stdit.py:109,118,121,128).
 //
-// Design (MI355X): one 512-thread workgroup (8 wave64) per BM x BN output tile, 1 workgroup / CU.
+// Design (MI355X): one 512-thread workgroup (8 wave64) per BM x BN output tile, 1 workgroup / CU (gemm_wide.h).
 //   - tile 256 tokens x 288 channels: 1152 = 4*288, 3456 = 12*288, 4608 = 16*288, so with
 //     M = 16384 every Linear of the STDiT block is an exact multiple of 256 workgroups (no tail wave);
 //     intensity 256*288/(256+288) = 135 MAC/B of L2->LDS traffic.
-//   - operands are both K-contiguous ([M,Kp] and [N,Kp] int8), staged HBM/L2 -> registers -> LDS in
-//     16-byte chunks, double-buffered (loads of tile t+1 fly under the MFMAs of tile t, one barrier/tile),
-//     LDS rows XOR-swizzled at 16-byte granularity so every ds_read_b128 fragment read is conflict-free.
-//   - MFMA v_mfma_i32_32x32x32_i8 with the WEIGHT fragment as the A operand and the TOKEN fragment as
+//   - operands are both K-contiguous ([M,Kp] and [N,Kp] int8), staged L2 -> LDS by LDS-DMA (buffer_load ... lds) in
+//     whole 128-byte lines per row and stage, double-buffered, one barrier per stage; LDS rows XOR-swizzled at
+//     16-byte granularity so every ds_read_b128 fragment read is conflict-free.
+//   - MFMA v_mfma_i32_16x16x64_i8 with the WEIGHT fragment as the A operand and the TOKEN fragment as
 //     the B operand, i.e. each wave computes D^T[n][m]: a lane then owns ONE token (column) and four
-//     consecutive channels per accumulator quad -> per-token dequant terms are lane constants and the
-//     fp16 result is stored as 8-byte pieces of a row.
-//   - blockIdx -> tile map is XCD-aware (8 XCDs, private L2s): consecutive tiles (n fastest) of one token
-//     panel go to the same XCD so the 295 KB activation panel is fetched into that L2 once.
-//   - W4A8: nibble-packed weights are expanded to int8 while being staged (layout in pack.hip).
+//     consecutive channels per accumulator quad -> per-token dequant terms are lane constants.
+//   - blockIdx -> tile map is XCD-aware (8 XCDs, private L2s; xcd_tile in gemm_common.h).
+//   - W4A8: nibble-packed weights travel as nibbles through LDS and are expanded to int8 operand words in registers
+//     (layout in pack.hip).
+//   - Launches whose 128-row tiles all fit ONE round of the 256 CUs (PixArt-Sigma's N = 1152 Linears at M = 8192: 128
+//     tiles of 256 rows = half the chip idle; the batched prompt K/V of 120-300 rows) take the 128 x 288 form of the same
+//     kernel (32 x 144 wave tiles): twice the workgroups, half the k-loop work each.  Same arithmetic per output
+//     element, bit-identical results (tested).
 //
 // Roofline: MFMA-bound (int8 dense peak 5.03 POPS); algorithmic bytes M*K + N*K(/2) + 2*M*N (+2*M*N
 // when a residual is read).
 #include "gemm_wide.h"
+
+// Tile height by shape.  A 128-row tile costs ~0.62 of a 256-row one (tools/gemm_half_tiles.py: 17.2 vs 23.1 us at
+// K = 1152, 45.1 vs 60.2 us at K = 4608 for one round), so it wins when it brings idle CUs in - fewer than 5/8 as many
+// rounds of the 256 CUs per 256-row round: every launch whose 128-row tiles fit ONE round (M = 8192, N = 1152: 128
+// -> 256 workgroups), and 1.5-round launches such as N = 3456 at M = 8192 (384 -> 768 tiles: 45.3 vs 48.2 us).
+static bool vq_half_tiles(int M, int N, int sets) {
+    const long nt = (long)((N + 287) / 288) * sets;
+    const long r128 = (((M + 127) / 128) * nt + 255) / 256, r256 = (((M + 255) / 256) * nt + 255) / 256;
+    return r128 * 5 < r256 * 8;
+}
+template <bool W4>
+static int launch_gemm_auto(const GemmArgs& a, hipStream_t st, int variant) {
+    const int sets = a.nbatch > 1 ? a.nbatch : a.ngroups > 1 ? a.ngroups : 1;
+    const bool half = variant == 16 || (variant == VQ_GEMM_DEFAULT && vq_half_tiles(a.M, a.N, sets));
+    if (half) return launch_gemm_wide<128, 288, 4, 2, true, W4>(a, st);
+    return launch_gemm_wide<256, 288, 4, 2, true, W4>(a, st);
+}
 extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R, const void* wq,
                           const float* sw, const int32_t* zw, const int32_t* cs, const float* bias, void* out,
                           int ldo, const void* resid, const float* gate, int rows_per_gate, int M, int N, int K,
@@ -44,10 +64,11 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
                ldo, rows_per_gate > 0 ? rows_per_gate : 1, M, N, K, Kp, epilogue, 0};
     hipStream_t st = (hipStream_t)stream;
     switch (variant) {
-        case VQ_GEMM_DEFAULT:
-        case 11:  // full-line double buffer: 128 bytes of k per row and stage, staggered DMA issue
-            if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, true, true>(a, st);
-            return launch_gemm_wide<256, 288, 4, 2, true>(a, st);
+        case VQ_GEMM_DEFAULT:  // tile height by shape (vq_half_tiles)
+        case 11:               // 256 x 288 tile: full-line double buffer, 128 bytes of k per row and stage, staggered DMA issue
+        case 16:               // 128 x 288 tile of the same kernel
+            if (w_bits <= 4) return launch_gemm_auto<true>(a, st, variant);
+            return launch_gemm_auto<false>(a, st, variant);
         default:
             break;
     }
@@ -72,7 +93,7 @@ extern "C" int vq_gemm_i8_batched(const int8_t* xq, const float* sx, const int32
     a.bs_w = (long)N * Kp;
     a.bs_ch = N;
     a.bs_out = (long)M * N;
-    return launch_gemm_wide<256, 288, 4, 2, true>(a, (hipStream_t)stream);
+    return launch_gemm_auto<false>(a, (hipStream_t)stream, VQ_GEMM_DEFAULT);
 }
 
 // ngroups (2 or 3) independent Linears of one shape in one grid: out_g [M, N] = dequant(xq_g . wq_g^T) + bias_g, written
@@ -100,6 +121,6 @@ extern "C" int vq_gemm_i8_grouped(int ngroups, const int8_t* const* xq, const fl
         a.grp[g - 1] = GemmArgs::Group{xq[g], sx[g], zx[g], R[g], (const uint8_t*)wq[g], sw[g], zw[g], cs[g],
                                        bias ? bias[g] : nullptr, (half_t*)out + (size_t)g * N};
     hipStream_t st = (hipStream_t)stream;
-    if (w_bits <= 4) return launch_gemm_wide<256, 288, 4, 2, true, true>(a, st);
-    return launch_gemm_wide<256, 288, 4, 2, true>(a, st);
+    if (w_bits <= 4) return launch_gemm_auto<true>(a, st, VQ_GEMM_DEFAULT);
+    return launch_gemm_auto<false>(a, st, VQ_GEMM_DEFAULT);
 }

@@ -1,4 +1,5 @@
-// gemm_wide.h - the full-line ring kernel (256 x 288 tile, 8 waves); see csrc/gemm_i8.hip for the design notes.
+// gemm_wide.h - the full-line ring kernel (256 x 288 tile, 8 waves of 64 x 144; 128 x 288 with 32 x 144 wave tiles for
+// launches that would otherwise leave half the CUs without a workgroup); see csrc/gemm_i8.hip for the design notes.
 #pragma once
 #include "gemm_common.h"
 
@@ -28,7 +29,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     constexpr int PLAST = PIECES - (PPW - 1) * NW;
     constexpr int BARJ = TN - 2;                      // after the last fragment read of the current stage
     constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (next tile)
-    static_assert(TM == 4 && TN >= 3 && TN % 3 == 0, "fragment rings below");
+    static_assert((TM == 4 || TM == 2) && TN >= 3 && TN % 3 == 0, "fragment rings below");
     static_assert(BN * WROW % 1024 == 0 && STAGE % 128 == 0, "whole pieces, 128-byte aligned stages");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
 
@@ -204,19 +205,19 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
             else if (H == 0) w[(j + 2) % 3] = ldw(cur, 1, j + 2 - TN);                                     \
             else if (more) w[(j + 2) % 3] = ldw(nxt, 0, j + 2 - TN);                                       \
             if (!(ABL & 8) && (H == 0 || more)) {                                                                          \
-                if (j == TN - 2) { XN[0] = ldx(H == 0 ? cur : nxt, 1 - H, 0); XN[1] = ldx(H == 0 ? cur : nxt, 1 - H, 1); } \
-                if (j == TN - 1) { XN[2] = ldx(H == 0 ? cur : nxt, 1 - H, 2); XN[3] = ldx(H == 0 ? cur : nxt, 1 - H, 3); } \
+                if (j == TN - 2) { _Pragma("unroll") for (int i = 0; i < TM / 2; ++i) XN[i] = ldx(H == 0 ? cur : nxt, 1 - H, i); } \
+                if (j == TN - 1) { _Pragma("unroll") for (int i = TM / 2; i < TM; ++i) XN[i] = ldx(H == 0 ? cur : nxt, 1 - H, i); } \
             }                                                                                              \
             const int4v wv_ = wop(w[j % 3]);                                                               \
             if (ABL & 2) {                                                                                 \
-                asm volatile("" ::"v"(wv_), "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]));                   \
+                asm volatile("" ::"v"(wv_), "v"(X[0]), "v"(X[TM / 2]), "v"(X[TM - 1]));                    \
             } else {                                                                                       \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
                     acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv_, X[i], acc[j][i], 0, 0, 0);      \
             }                                                                                              \
-            if (j >= TN - 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                            \
+            if (j >= TN - 2) __builtin_amdgcn_sched_group_barrier(0x100, 1 + TM / 2, 0);                   \
             else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                            \
         }                                                                                                  \
     }
     // ABL & 32 (experiment): static priority for the later-dispatched half of the waves - measured 12 % SLOWER
