@@ -413,6 +413,35 @@ def test_smoothed_quantizers_fast_division_is_bit_identical(ops, dev, n_tok):
     same(ops.gelu_rowquant(x4, s=s4), ops.gelu_rowquant(x4, s=s4, fast_div=False))
 
 
+@pytest.mark.parametrize("n_tok", [16384, 131])
+def test_smoothed_outputs_of_one_pass_equal_the_per_output_kernels(ops, dev, n_tok):
+    """Two / three smoothed outputs from ONE pass over the rows (smooth_rowquant_multi_kernel: vectors in LDS, the row
+    read and normalised once) against the one-output launches of smooth_rowquant_half_kernel: the same per-lane
+    expressions in the same order, so codes, steps, zero points, row sums and the modulated activation are equal bit
+    for bit - full size and an odd row count."""
+    C = 1152
+    g = torch.Generator().manual_seed(7 + n_tok)
+    x = h16(1, n_tok, C, scale=2.5, seed=n_tok).to(dev)
+    sm = [torch.exp(torch.randn(C, generator=g) * 0.7).float().to(dev) for _ in range(3)]
+    shift = h16(1, C, scale=0.3, seed=5).float().to(dev)
+    scale = h16(1, C, scale=0.3, seed=6).float().to(dev)
+
+    def same(a, b):
+        for f in ("xq", "sx", "zx", "R"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), f
+
+    for smooth in (sm, sm[:2]):
+        for nb in (8, 6):
+            multi = ops.rowquant_multi(x, smooth, n_bits=nb)
+            for qa, s in zip(multi, smooth):
+                same(qa, ops.rowquant(x, s=s, n_bits=nb))
+        multi, xm = ops.ln_modulate_rowquant(x, shift, scale, 1e-6, smooth=smooth, want_xm=True)
+        for qa, s in zip(multi, smooth):
+            one, xm1 = ops.ln_modulate_rowquant(x, shift, scale, 1e-6, smooth=[s], want_xm=True)
+            same(qa, one[0])
+            assert torch.equal(xm, xm1)
+
+
 # ----------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, scale):
     # q [n,Lq,H,D] k,v [n,Lk,H,D] ; fp32 softmax  (blocks.py:179-187)

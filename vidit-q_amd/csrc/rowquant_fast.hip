@@ -748,6 +748,170 @@ static bool launch_smooth_half(const half_t* x, const float* shift, const float*
 }
 
 // ---------------------------------------------------------------------------
+// Two or three smoothed outputs of ONE pass over the rows (round 3).  smooth_rowquant_half_kernel above gives every
+// output its own workgroups: the q / k / v copies re-read the row from L2 / MALL and redo the LayerNorm, and a launch
+// moved 3 x 38 MB + 57 MB (LN + modulate + 3 outputs: 38 us = 2.5 TB/s of useful bytes).  Here a half-wave still owns a
+// row and still computes the same per-lane expressions in the same order (codes, steps, zero points and row sums are
+// bit-identical to that kernel's - tested), but the smoothing vectors, their reciprocals and (LN) the modulation
+// vectors of all outputs live in LDS (8 x 4.6 KB at C = 1152, staged once per workgroup of NWV waves; one
+// conflict-free ds_read_b128 per four channels, both half-waves reading the same words), so one set of row registers
+// serves every output: the row is read once, normalised once, and quantized NOUT times.
+// ---------------------------------------------------------------------------
+template <int NIT, bool LN, int NOUT, int RPW, int NWV>
+__global__ __launch_bounds__(64 * NWV, 4) void smooth_rowquant_multi_kernel(
+    const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
+    LnqFastOut o, half_t* __restrict__ xm_out, int n_tok, int n_bits, int32_t* status) {
+    constexpr int C = 128 * NIT;
+    extern __shared__ __attribute__((aligned(16))) float smq_lds[];   // [NOUT][s | r][C], then (LN) [1 + scale | shift][C]
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const bool hi = lane >= 32;
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int cx = (n_bits == 8) ? 128 : 0;
+    const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
+    const float invC = 1.0f / (float)C;
+    const int pair0 = (blockIdx.x * NWV + (threadIdx.x >> 6)) * RPW;
+    half4 hn[NIT];
+    {                                                      // the first rows are requested before the staging loads
+        int t = pair0 * 2 + (hi ? 1 : 0);
+        t = t < n_tok ? t : n_tok - 1;
+        const half_t* row = x + (size_t)t * C + hl * 4;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) hn[i] = *reinterpret_cast<const half4*>(row + i * 128);
+    }
+    for (int i = threadIdx.x; i < C / 4; i += 64 * NWV) {
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) {
+            reinterpret_cast<float4v*>(smq_lds + (2 * j) * C)[i] = reinterpret_cast<const float4v*>(o.s[j])[i];
+            reinterpret_cast<float4v*>(smq_lds + (2 * j + 1) * C)[i] = reinterpret_cast<const float4v*>(o.r[j])[i];
+        }
+        if constexpr (LN) {
+            float4v sc = reinterpret_cast<const float4v*>(scale)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc[e] = 1.0f + sc[e];
+            reinterpret_cast<float4v*>(smq_lds + (2 * NOUT) * C)[i] = sc;
+            reinterpret_cast<float4v*>(smq_lds + (2 * NOUT + 1) * C)[i] = reinterpret_cast<const float4v*>(shift)[i];
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < RPW; ++it) {
+        if ((pair0 + it) * 2 >= n_tok) break;              // wave-uniform
+        int tok = (pair0 + it) * 2 + (hi ? 1 : 0);
+        const bool live = tok < n_tok;
+        if (!live) tok = n_tok - 1;                        // odd tail: the upper half re-does the last row, writes nothing
+        float w[NIT][4];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[i][e] = (float)hn[i][e];
+        if (it + 1 < RPW) {                                // next pair's rows fly under this pair's arithmetic
+            int t = (pair0 + it + 1) * 2 + (hi ? 1 : 0);
+            t = t < n_tok ? t : n_tok - 1;
+            const half_t* row = x + (size_t)t * C + hl * 4;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) hn[i] = *reinterpret_cast<const half4*>(row + i * 128);
+        }
+        if constexpr (LN) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += w[i][e];
+            RQH_REDUCE2(float, vq_addf, sum)
+            const float mu = sum * invC;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = w[i][e] - mu;
+                    sq += d * d;
+                }
+            RQH_REDUCE2(float, vq_addf, sq)
+            const float rstd = __fdiv_rn(1.0f, __fsqrt_rn(sq * invC + ln_eps));
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const float4v sc4 = *reinterpret_cast<const float4v*>(smq_lds + (2 * NOUT) * C + i * 128 + hl * 4);
+                const float4v sh4 = *reinterpret_cast<const float4v*>(smq_lds + (2 * NOUT + 1) * C + i * 128 + hl * 4);
+                half4 hm;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = (w[i][e] - mu) * rstd;
+                    const float u = y * sc4[e] + sh4[e];
+                    hm[e] = (half_t)u;
+                    w[i][e] = u;
+                }
+                if (xm_out && live) *reinterpret_cast<half4*>(xm_out + (size_t)tok * C + hl * 4 + i * 128) = hm;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) {
+            float q[NIT][4];
+            float vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const float4v s4 = *reinterpret_cast<const float4v*>(smq_lds + (2 * j) * C + i * 128 + hl * 4);
+                const float4v r4 = *reinterpret_cast<const float4v*>(smq_lds + (2 * j + 1) * C + i * 128 + hl * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q[i][e] = rq_div_rcp(w[i][e], s4[e], r4[e]);
+                    vmin = fminf(vmin, q[i][e]);
+                    vmax = fmaxf(vmax, q[i][e]);
+                }
+            }
+            RQH_REDUCE2(float, fminf, vmin)
+            RQH_REDUCE2(float, fmaxf, vmax)
+            float delta, zp;
+            bool small;
+            vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+            if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
+            const float inv = __fdiv_rn(1.0f, delta);
+            const int izx = (int)zp - cx;
+            int8_t* qrow = o.xq[j] + (size_t)tok * C + hl * 4;
+            uint32_t csum = 0;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float c = rq_round_div(q[i][e], inv, delta) + zp;
+                    if (qmax != 255.0f) c = __builtin_amdgcn_fmed3f(c, 0.0f, qmax);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(c, e, pk);
+                }
+                csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
+                if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
+            }
+            int cs = (int)csum;
+            RQH_REDUCE2(int, vq_addi, cs)
+            if (hl == 0 && live) {
+                o.sx[j][tok] = delta;
+                o.zx[j][tok] = izx;
+                o.R[j][tok] = cs - cx * C - C * izx;
+            }
+        }
+    }
+}
+
+template <bool LN, int NOUT>
+static bool launch_smooth_multi(const half_t* x, const float* shift, const float* scale, float eps, const LnqFastOut& o,
+                                half_t* xm, int n_tok, int C, int n_bits, int32_t* status, hipStream_t st) {
+    constexpr int RPW = 2, NWV = 8;
+    const size_t lds = (size_t)(2 * NOUT + (LN ? 2 : 0)) * C * sizeof(float);
+    dim3 grid((n_tok + 2 * NWV * RPW - 1) / (2 * NWV * RPW));
+#define SMM_GO(N_)                                                                                                   \
+    hipLaunchKernelGGL((smooth_rowquant_multi_kernel<N_, LN, NOUT, RPW, NWV>), grid, dim3(64 * NWV), lds, st, x, shift, \
+                       scale, eps, o, xm, n_tok, n_bits, status)
+    switch (C / 128) {                                     // <= 8 x 5 KB of LDS: inside the 64 KB every kernel may use
+        case 6: SMM_GO(6); break;
+        case 8: SMM_GO(8); break;
+        case 9: SMM_GO(9); break;
+        case 10: SMM_GO(10); break;
+        default: return false;
+    }
+#undef SMM_GO
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // host dispatch (called from the C ABI entry points in rowquant.hip)
 // ---------------------------------------------------------------------------
 template <int MAXCH>
@@ -843,6 +1007,8 @@ bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float 
             LnqFastOut o{};
             for (int j = 0; j < n_out; ++j)
                 o.s[j] = s[j], o.r[j] = s_rcp[j], o.xq[j] = xq[j], o.sx[j] = sx[j], o.zx[j] = zx[j], o.R[j] = R[j];
+            if (n_out == 3 && launch_smooth_multi<true, 3>(x, shift, scale, eps, o, xm, n_tok, C, n_bits, status, st)) return true;
+            if (n_out == 2 && launch_smooth_multi<true, 2>(x, shift, scale, eps, o, xm, n_tok, C, n_bits, status, st)) return true;
             if (launch_smooth_half<true, 4>(x, shift, scale, eps, o, n_out, xm, n_tok, C, n_bits, status, st)) return true;
         }
     }
@@ -884,5 +1050,7 @@ bool vq_rowquant_smooth_multi_fast(const half_t* x, int n_out, const float* cons
     LnqFastOut o{};
     for (int j = 0; j < n_out; ++j)
         o.s[j] = s[j], o.r[j] = s_rcp[j], o.xq[j] = xq[j], o.sx[j] = sx[j], o.zx[j] = zx[j], o.R[j] = R[j];
+    if (n_out == 3 && launch_smooth_multi<false, 3>(x, nullptr, nullptr, 0.f, o, nullptr, n_tok, C, n_bits, status, st)) return true;
+    if (n_out == 2 && launch_smooth_multi<false, 2>(x, nullptr, nullptr, 0.f, o, nullptr, n_tok, C, n_bits, status, st)) return true;
     return launch_smooth_half<false, 2>(x, nullptr, nullptr, 0.f, o, n_out, nullptr, n_tok, C, n_bits, status, st);
 }
