@@ -466,6 +466,23 @@ def test_tiny_pixart_dpm_solver_trajectory(dev, ops, parity):
     # 5 guided steps (cfg 4.5 amplifies the cond/uncond difference) on fp16 activations and fp16 timesteps
     parity["tiny_pixart_ms/dpm_final"] = {"vs_ref_fp32": rel_l2(out.cpu().float(), g["dpm_final"])}
     assert rel_l2(out.cpu().float(), g["dpm_final"]) < 2.5e-3     # recorded 1.9e-3
+    # the same loop with every forward replayed from ONE captured HIP graph (graph.GraphedModel: what the t2i bench leg
+    # runs - the ~700 launches of a full-size forward are host-bound from Python): equal bit for bit, and a changed
+    # keyword argument (another mask) is a new capture, not a stale replay
+    from viditq_amd.graph import GraphedModel
+    gm = GraphedModel(qnn.forward_with_dpmsolver, qnn=qnn)
+    kw = dict(condition=g["y"][:1].half().to(dev), uncondition=g["dpm_null_y"].half().to(dev), cfg_scale=4.5)
+    mask1 = g["mask"][:1].to(dev)
+    out_g = DPMS_sigma(gm, model_kwargs=dict(data_info=None, mask=mask1), **kw).sample(
+        g["dpm_z"].to(dev), steps=5, order=2, skip_type="time_uniform", method="multistep")
+    assert torch.equal(out_g, out)
+    assert len(gm.graphs) == 1
+    mask2 = mask1.clone()
+    mask2[0, -3:] = 0
+    eager2 = DPMS_sigma(qnn.forward_with_dpmsolver, model_kwargs=dict(data_info=None, mask=mask2), **kw).sample(
+        g["dpm_z"].to(dev), steps=3, order=2)
+    graph2 = DPMS_sigma(gm, model_kwargs=dict(data_info=None, mask=mask2), **kw).sample(g["dpm_z"].to(dev), steps=3, order=2)
+    assert torch.equal(graph2, eager2) and len(gm.graphs) == 2 and not torch.equal(graph2, out)
 
 
 def test_prompt_cache_is_exact(dev, ops):

@@ -24,6 +24,7 @@ ap.add_argument("--w-bits", type=int, default=4)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--depth", type=int, default=28)
 ap.add_argument("--size", type=int, default=1024)
+ap.add_argument("--graph", action="store_true", help="replay the forward as one captured HIP graph (graph.GraphedModel) instead of eager launches")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 lat = a.size // 8
@@ -52,15 +53,18 @@ with torch.no_grad():
     mask = torch.zeros(1, Lp, dtype=torch.int64, device=dev)
     mask[0, :180] = 1
     z = torch.randn(1, 4, lat, lat, generator=g).to(dev)
-    solver = DPMS_sigma(qnn.forward_with_dpmsolver, condition=y, uncondition=null_y, cfg_scale=4.5,
+    from viditq_amd.graph import GraphedModel
+    solver = DPMS_sigma(GraphedModel(qnn.forward_with_dpmsolver, qnn=qnn) if a.graph else qnn.forward_with_dpmsolver, condition=y, uncondition=null_y, cfg_scale=4.5,
                         model_kwargs=dict(data_info=None, mask=mask))
     solver.sample(z, steps=2, order=2)                     # warm-up: packing, caches
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = solver.sample(z, steps=a.steps, order=2)
+    t_host = time.perf_counter() - t0                      # host done enqueuing (the GPU may still be running)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     assert torch.isfinite(out).all()
     print(json.dumps({"workload": "PixArt-Sigma %dx%d W%dA8, %d tokens, Lp %d, DPM-Solver++ 2M, cfg 4.5, batched uncond|cond forward" % (
-        a.size, a.size, a.w_bits, (lat // 2) ** 2, Lp), "steps": a.steps, "depth": a.depth,
-        "steps_per_s": a.steps / el, "ms_per_step": el / a.steps * 1e3, "status_word": qnn.check_status()}))
+        a.size, a.size, a.w_bits, (lat // 2) ** 2, Lp), "steps": a.steps, "depth": a.depth, "hip_graph": a.graph,
+        "steps_per_s": a.steps / el, "ms_per_step": el / a.steps * 1e3,
+        "host_enqueue_ms_per_step": t_host / a.steps * 1e3, "status_word": qnn.check_status()}))

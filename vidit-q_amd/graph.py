@@ -106,3 +106,100 @@ class GraphedSampler:
             g = self.graphs[r] = StepGraph(self.qnn, x, self.yc, self.yu, self.mask, t_id,
                                            two_streams=self.two_streams)
         return g.run(x, t_id)
+
+
+def _ident(v):
+    """Identity of a keyword argument for the graph key: tensors by storage and version (their CONTENT is baked into the
+    capture through host-side decisions such as the prompt-token selection), containers recursively, scalars by value."""
+    if torch.is_tensor(v):
+        return ("t", v.data_ptr(), v._version, tuple(v.shape), str(v.dtype))
+    if isinstance(v, dict):
+        return tuple((k, _ident(x)) for k, x in sorted(v.items()))
+    if isinstance(v, (list, tuple)):
+        return tuple(_ident(x) for x in v)
+    return v
+
+
+class ForwardGraph:
+    """One forward ``fn(x, t, y, **kwargs)`` as a replayable HIP graph with static x / t / y buffers."""
+
+    def __init__(self, fn, x, t, y, kwargs, warmup: int = 2):
+        self.x, self.t, self.y = x.clone(), t.clone(), y.clone()
+        self.kwargs = kwargs
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup + 1):                  # packs weights, fills the host-side caches (mask selection, ...)
+                fn(self.x, self.t, self.y, **kwargs)
+            side.synchronize()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.out = fn(self.x, self.t, self.y, **kwargs)
+
+    def run(self, x, t, y):
+        self.x.copy_(x)
+        self.t.copy_(t)
+        self.y.copy_(y)
+        self.graph.replay()
+        return self.out
+
+
+class GraphedModel:
+    """``model(x, t, y, **kwargs)`` for a sampling loop that calls one forward per step with the same shapes and the same
+    keyword arguments (the t2i DPM-Solver loop, quant_txt2img.py:130-153: ``DPMS_sigma(GraphedModel(qnn.forward_with_dpmsolver),
+    ...)``).  The ~540 launches of a PixArt forward are captured once per (shapes, keyword identities, smooth-quant
+    time-range, pack epoch) and replayed with the new latent / timestep / text embedding copied into the static inputs;
+    the result is a fresh tensor each call (multistep solvers keep earlier outputs).  Bit-identical to eager launches
+    (tested).  For forwards whose GPU time is below the ~25 us per launch Python needs (small latents).  NOT what the
+    1024 x 1024 bench leg uses: there a forward is 19 ms of GPU work, eager launches stay ahead of it (49.1 steps/s)
+    and a replay costs more than it saves (44.8 steps/s: ~12 us of host time per graph node at launch, measured on the
+    2300-node STDiT graph as 27 ms per replay, and a ~1.5 ms bubble per step in front of the first node)."""
+
+    def __init__(self, fn, qnn=None, max_graphs: int = 8):
+        self.fn, self.qnn = fn, qnn if qnn is not None else getattr(fn, "__self__", None)
+        self.graphs: Dict[Hashable, ForwardGraph] = {}
+        self.max_graphs = max_graphs
+        self._epoch = None
+
+    def _range_of(self, t_id) -> int:
+        """Smooth-quant time-range the forward will run in: from ``timestep_id`` when the call passes one
+        (QuantModel.forward), else from the state the script set on the layers (set_timestep_id_for_quantlayer)."""
+        root = self.qnn
+        if root is None or not hasattr(root, "modules"):
+            return 0
+        from .qdiff.models.quant_layer import find_interval
+        for layer in root.modules():
+            if getattr(layer, "smooth_quant", False) and hasattr(layer, "timerange"):
+                if t_id is not None:
+                    return find_interval(layer.timerange, int(t_id))
+                return int(layer._range_and_alpha()[0])
+        return 0
+
+    def _host_visible_state(self) -> bool:
+        """A layer that keeps a RUNNING smooth-quant statistic at inference (the released t2i W4A8 plan leaves it on for
+        blocks.27.mlp.fc2, quant_txt2img.py:297-300) updates host-visible state in every forward: not capturable."""
+        root = self.qnn
+        if root is None or not hasattr(root, "modules"):
+            return False
+        return any(getattr(m, "smooth_quant_running_stat", False) and "momentum" in str(getattr(m, "channel_wise_scale_type", ""))
+                   for m in root.modules())
+
+    def __call__(self, x, t, y, **kwargs):
+        from .qdiff.models.quant_layer import PACK_EPOCH
+        if not x.is_cuda or self._host_visible_state():
+            return self.fn(x, t, y, **kwargs)
+        if self._epoch != PACK_EPOCH[0]:
+            self.graphs.clear()                          # captured graphs reference re-packed weight buffers
+            self._epoch = PACK_EPOCH[0]
+        kw = {k: v for k, v in kwargs.items() if k != "timestep_id"}
+        key = (tuple(x.shape), str(x.dtype), tuple(t.shape), str(t.dtype), tuple(y.shape), str(y.dtype), _ident(kw),
+               self._range_of(kwargs.get("timestep_id")))
+        g = self.graphs.get(key)
+        if g is None:
+            if len(self.graphs) >= self.max_graphs:
+                self.graphs.clear()
+            g = self.graphs[key] = ForwardGraph(self.fn, x, t, y, kwargs)
+            if self._epoch != PACK_EPOCH[0]:             # the first pass packed weights: the capture came after it
+                self._epoch = PACK_EPOCH[0]
+        return g.run(x, t, y).clone()
