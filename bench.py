@@ -277,8 +277,8 @@ def pixart_leg(dev, steps=4, w_bits=4, size=1024, Lp=300):
         mask = torch.zeros(1, Lp, dtype=torch.int64, device=dev)
         mask[0, :180] = 1
         z = torch.randn(1, 4, lat, lat, generator=g).to(dev)
-        # eager launches: a forward is 19 ms of GPU work, Python stays ahead of it; replaying it as a HIP graph
-        # (graph.GraphedModel) measured slower at this size (44.8 vs 49.1 steps/s)
+        # eager launches: a forward is 19.9 ms of GPU work and Python (10.9 ms of launches per step) stays ahead of it;
+        # replayed as a HIP graph (graph.GraphedModel) the step takes the same time (49.7 vs 50.3 steps/s)
         solver = DPMS_sigma(qnn.forward_with_dpmsolver, condition=y, uncondition=null_y, cfg_scale=4.5,
                             model_kwargs=dict(data_info=None, mask=mask))
         solver.sample(z, steps=2, order=2)                     # warm-up: packing, caches

@@ -151,10 +151,10 @@ class GraphedModel:
     ...)``).  The ~540 launches of a PixArt forward are captured once per (shapes, keyword identities, smooth-quant
     time-range, pack epoch) and replayed with the new latent / timestep / text embedding copied into the static inputs;
     the result is a fresh tensor each call (multistep solvers keep earlier outputs).  Bit-identical to eager launches
-    (tested).  For forwards whose GPU time is below the ~25 us per launch Python needs (small latents).  NOT what the
-    1024 x 1024 bench leg uses: there a forward is 19 ms of GPU work, eager launches stay ahead of it (49.1 steps/s)
-    and a replay costs more than it saves (44.8 steps/s: ~12 us of host time per graph node at launch, measured on the
-    2300-node STDiT graph as 27 ms per replay, and a ~1.5 ms bubble per step in front of the first node)."""
+    (tested).  At PixArt-Sigma 1024 x 1024 a forward is 19.9 ms of GPU work either way (50.3 steps/s eager, 49.7
+    replayed): eager Python launches need 10.9 ms of host time per step and stay ahead of the GPU, a replay needs 3.0 ms;
+    the replay pays when the forward is shorter than its ~25 us per launch from Python (small latents) or the host
+    is needed for something else."""
 
     def __init__(self, fn, qnn=None, max_graphs: int = 8):
         self.fn, self.qnn = fn, qnn if qnn is not None else getattr(fn, "__self__", None)

@@ -83,16 +83,23 @@ class DPMSolverPP:
         self.cfg_scale = float(cfg_scale)
         self.model_kwargs = dict(model_kwargs or {})
         self.ns = NoiseScheduleVP(linear_betas(diffusion_steps))
+        self._c2 = None                                   # (uncond | cond) text embedding, concatenated once
 
     # ---- model_wrapper: continuous time -> model input time, classifier-free guidance (:273-332)
     def _noise(self, x, t_cont: torch.Tensor):
         n = x.shape[0]
-        t_in = ((t_cont - 1.0 / self.ns.total_N) * 1000.0).to(x.device)
+        # the model-input time is computed on the host in fp32 (the same two roundings as the reference's tensor
+        # expression) and materialised by a fill kernel: a `.to(device)` of a host tensor here is a pageable copy that
+        # makes the host wait for ALL queued GPU work once per step
+        t_val = float((t_cont.float() - 1.0 / self.ns.total_N) * 1000.0)
         if self.cfg_scale == 1.0 or self.uncondition is None:
-            return self.model(x, t_in.expand(n), self.condition, **self.model_kwargs)
+            return self.model(x, torch.full((n,), t_val, dtype=torch.float32, device=x.device), self.condition,
+                              **self.model_kwargs)
         x2 = torch.cat([x, x])
-        c2 = torch.cat([self.uncondition, self.condition])
-        out = self.model(x2, t_in.expand(2 * n), c2, **self.model_kwargs)
+        if self._c2 is None or self._c2[0] is not self.condition or self._c2[1] is not self.uncondition:
+            self._c2 = (self.condition, self.uncondition, torch.cat([self.uncondition, self.condition]))
+        out = self.model(x2, torch.full((2 * n,), t_val, dtype=torch.float32, device=x.device), self._c2[2],
+                         **self.model_kwargs)
         noise_uncond, noise = out.chunk(2)
         return noise_uncond + self.cfg_scale * (noise - noise_uncond)
 
