@@ -56,14 +56,24 @@ __device__ __forceinline__ uint32_t rq_quant8(const float v[8], float inv, float
 // ---------------------------------------------------------------------------
 // plain per-token quantizer, B == 1
 // ---------------------------------------------------------------------------
-template <int MAXCH, bool HAS_S, bool HAS_ADD, bool GELU = false>
+// PAIR: x [2, n_tok, C] with the quantization grid of a token shared by its two samples (base_quantizer.py:185; the
+// t2i loop's uncond | cond batch): waves 2k and 2k + 1 of a workgroup take the two rows of one token and exchange their
+// min / max through LDS; outputs are indexed by row (sample * n_tok + token) with the shared step replicated, as the
+// generic kernel writes them.
+template <int MAXCH, bool HAS_S, bool HAS_ADD, bool GELU = false, bool PAIR = false>
 __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
     const half_t* __restrict__ x, const half_t* __restrict__ add_rows, int add_div, const float* __restrict__ s,
     const float* __restrict__ s_rcp, int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx,
     int32_t* __restrict__ R, float* __restrict__ zpf, int n_tok, int C, int Kp, int n_bits, int32_t* status) {
-    const int lane = threadIdx.x & 63;
-    const int tok = blockIdx.x * RQF_WAVES + (threadIdx.x >> 6);
-    if (tok >= n_tok) return;
+    static_assert(!PAIR || (!HAS_ADD && RQF_WAVES % 2 == 0), "pairs of waves; added rows are per token");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int tok = PAIR ? blockIdx.x * (RQF_WAVES / 2) + (wv >> 1) : blockIdx.x * RQF_WAVES + wv;
+    const bool live = tok < n_tok;
+    if (!live) {
+        if constexpr (!PAIR) return;
+        tok = n_tok - 1;                                // stays for the workgroup barrier below, writes nothing
+    }
+    if (PAIR && (wv & 1)) tok += n_tok;                 // row index of (sample 1, token)
     const float qmax = (float)((1 << n_bits) - 1);
     const int cx = (n_bits == 8) ? 128 : 0;
     const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
@@ -135,10 +145,20 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
     }
     vmin = wave_min_f(vmin);
     vmax = wave_max_f(vmax);
+    if constexpr (PAIR) {
+        __shared__ float pm[RQF_WAVES][2];
+        if (lane == 0) {
+            pm[wv][0] = vmin;
+            pm[wv][1] = vmax;
+        }
+        __syncthreads();
+        vmin = fminf(vmin, pm[wv ^ 1][0]);
+        vmax = fmaxf(vmax, pm[wv ^ 1][1]);
+    }
     float delta, zp;
     bool small;
     vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
-    if (small && lane == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
+    if (small && lane == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
     const float inv = __fdiv_rn(1.0f, delta);
     const int izx = (int)zp - cx;
 
@@ -153,13 +173,13 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
             for (int e = 0; e < 8; ++e) v[e] = (HAS_S || HAS_ADD) ? w[i][e] : (float)h[i][e];
             uint2 p;
             csum += rq_quant8(v, inv, delta, zp, qmax, flip, p);
-            *reinterpret_cast<uint2*>(qrow + c0) = p;
+            if (live) *reinterpret_cast<uint2*>(qrow + c0) = p;
         } else if (c0 < Kp) {
-            *reinterpret_cast<uint2*>(qrow + c0) = make_uint2(0u, 0u);
+            if (live) *reinterpret_cast<uint2*>(qrow + c0) = make_uint2(0u, 0u);
         }
     }
     const int rs = wave_sum_i((int)csum) - cx * C;
-    if (lane == 0) {
+    if (lane == 0 && live) {
         sx[tok] = delta;
         zx[tok] = izx;
         R[tok] = rs - C * izx;
@@ -285,7 +305,11 @@ static bool launch_rq_smooth_lds(const half_t* x, const float* s, const float* s
 // elements per lane, 8-byte coalesced loads), so the per-row sequence runs once for two rows and every lane
 // is busy.
 // ---------------------------------------------------------------------------
-template <int NIT>   // C = 128 * NIT
+// PAIR (round 3): the two rows of a wave are the SAME token of a batch of two (x [2, n_tok, C]: the t2i loop's
+// uncond | cond forward), whose quantization grid the reference shares over the batch (base_quantizer.py:185): the
+// min / max of the two half-waves are combined, everything else stays per row.  The generic B > 1 kernel this
+// replaces for B == 2 took 24 us per launch at 2 x 4096 rows (13.5 % of a PixArt-Sigma step).
+template <int NIT, bool PAIR = false>   // C = 128 * NIT
 __global__ __launch_bounds__(RQF_THREADS) void rowquant_half_kernel(const half_t* __restrict__ x, int8_t* __restrict__ xq,
                                                                     float* __restrict__ sx, int32_t* __restrict__ zx,
                                                                     int32_t* __restrict__ R, float* __restrict__ zpf,
@@ -293,9 +317,11 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_half_kernel(const half_t
     constexpr int C = 128 * NIT;
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const bool hi = lane >= 32;
-    int tok = (blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)) * 2 + (hi ? 1 : 0);
+    int tok = PAIR ? blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)
+                   : (blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)) * 2 + (hi ? 1 : 0);
     const bool live = tok < n_tok;
     if (!live) tok = n_tok - 1;                       // odd tail: the upper half re-does the last row, writes nothing
+    if (PAIR && hi) tok += n_tok;                     // row index of (sample 1, token)
     const float qmax = (float)((1 << n_bits) - 1);
     const int cx = (n_bits == 8) ? 128 : 0;
     const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
@@ -331,8 +357,13 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_half_kernel(const half_t
         const float m1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmax, 16));
         const float m2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmax, 32));
         const float m3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bmax, 48));
-        vmin = hi ? fminf(n2, n3) : fminf(n0, n1);
-        vmax = hi ? fmaxf(m2, m3) : fmaxf(m0, m1);
+        if constexpr (PAIR) {
+            vmin = fminf(fminf(n0, n1), fminf(n2, n3));
+            vmax = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        } else {
+            vmin = hi ? fminf(n2, n3) : fminf(n0, n1);
+            vmax = hi ? fmaxf(m2, m3) : fmaxf(m0, m1);
+        }
     }
     float delta, zp;
     bool small;
@@ -506,7 +537,7 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_fast_kernel(
         const T_ r3_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 48));                       \
         v_ = hi ? OP_(r2_, r3_) : OP_(r0_, r1_);                                                        \
     }
-template <int NIT>
+template <int NIT, bool PAIR = false>   // PAIR: see rowquant_half_kernel; shift / scale [2, C], one row per sample
 __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
     const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
     int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R, int n_tok,
@@ -514,9 +545,15 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
     constexpr int C = 128 * NIT;
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const bool hi = lane >= 32;
-    int tok = (blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)) * 2 + (hi ? 1 : 0);
+    int tok = PAIR ? blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)
+                   : (blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)) * 2 + (hi ? 1 : 0);
     const bool live = tok < n_tok;
     if (!live) tok = n_tok - 1;
+    if (PAIR && hi) {
+        tok += n_tok;
+        shift += C;
+        scale += C;
+    }
     const float qmax = (float)((1 << n_bits) - 1);
     const int cx = (n_bits == 8) ? 128 : 0;
     const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
@@ -563,6 +600,10 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
     }
     RQH_REDUCE2(float, fminf, vmin)
     RQH_REDUCE2(float, fmaxf, vmax)
+    if constexpr (PAIR) {                             // one grid for the token's two samples
+        vmin = fminf(vmin, __shfl_xor(vmin, 32));
+        vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+    }
     float delta, zp;
     bool small;
     vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
@@ -958,6 +999,51 @@ bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, cons
     if (Kp <= 512) launch_rq<1>(hs, ha, grid, st, x, add_rows, add_div, s, s_rcp, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
     else if (Kp <= 1536) launch_rq<3>(hs, ha, grid, st, x, add_rows, add_div, s, s_rcp, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
     else launch_rq<9>(hs, ha, grid, st, x, add_rows, add_div, s, s_rcp, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status);
+    return true;
+}
+
+// x [2, n_tok, C], grids shared by the two samples of a token (B == 2 of the C ABI): the half-wave kernel at the block
+// widths, one row per wave with an LDS exchange between partner waves elsewhere
+bool vq_rowquant_pair_fast(const half_t* x, int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf, int n_tok, int C,
+                           int Kp, int n_bits, int32_t* status, hipStream_t st) {
+    if (C > 4608 || Kp > 4608) return false;
+    if (C % 128 == 0 && Kp == C && (C == 1152 || C == 1024 || C == 1280 || C == 768)) {
+        dim3 g2((n_tok + RQF_WAVES - 1) / RQF_WAVES);
+#define RQP_GO(N_) hipLaunchKernelGGL((rowquant_half_kernel<N_, true>), g2, dim3(RQF_THREADS), 0, st, x, xq, sx, zx, R, zpf, n_tok, n_bits, status)
+        switch (C / 128) {
+            case 6: RQP_GO(6); break;
+            case 8: RQP_GO(8); break;
+            case 9: RQP_GO(9); break;
+            default: RQP_GO(10); break;
+        }
+#undef RQP_GO
+        return true;
+    }
+    dim3 grid((n_tok + RQF_WAVES / 2 - 1) / (RQF_WAVES / 2)), block(RQF_THREADS);
+#define RQP_GO(M_)                                                                                                   \
+    hipLaunchKernelGGL((rowquant_fast_kernel<M_, false, false, false, true>), grid, block, 0, st, x, (const half_t*)nullptr, \
+                       1, (const float*)nullptr, (const float*)nullptr, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status)
+    if (Kp <= 512) RQP_GO(1);
+    else if (Kp <= 1536) RQP_GO(3);
+    else RQP_GO(9);
+#undef RQP_GO
+    return true;
+}
+
+bool vq_lnq_pair_fast(const half_t* x, const float* shift, const float* scale, float eps, int8_t* xq, float* sx,
+                      int32_t* zx, int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+    if (Kp != C || !(C == 1152 || C == 1024 || C == 1280 || C == 768)) return false;
+    dim3 g2((n_tok + RQF_WAVES - 1) / RQF_WAVES);
+#define LNP_GO(N_)                                                                                                    \
+    hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, true>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
+                       xq, sx, zx, R, n_tok, n_bits, status)
+    switch (C / 128) {
+        case 6: LNP_GO(6); break;
+        case 8: LNP_GO(8); break;
+        case 9: LNP_GO(9); break;
+        default: LNP_GO(10); break;
+    }
+#undef LNP_GO
     return true;
 }
 
