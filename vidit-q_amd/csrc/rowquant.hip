@@ -21,7 +21,10 @@ bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, cons
                       int32_t* status, hipStream_t st);
 bool vq_rowquant_pair_fast(const half_t* x, int8_t* xq, float* sx, int32_t* zx, int32_t* R, float* zpf, int n_tok, int C,
                            int Kp, int n_bits, int32_t* status, hipStream_t st);
-bool vq_lnq_pair_fast(const half_t* x, const float* shift, const float* scale, float eps, int8_t* xq, float* sx,
+bool vq_rowquant_pair_smooth_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
+                                  int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
+bool vq_lnq_pair_fast(const half_t* x, const float* shift, const float* scale, float eps, const float* s, const float* s_rcp,
+                      int8_t* xq, float* sx,
                       int32_t* zx, int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
 bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float eps, int n_out,
                  const float* const* s, const float* const* s_rcp, int8_t* const* xq, float* const* sx,
@@ -441,6 +444,10 @@ extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int a
     if (B == 2 && !delta_in && !add_rows && !s &&
         vq_rowquant_pair_fast((const half_t*)x, xq, sx, zx, R, zpf, n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
         return vq_check_launch();
+    if (B == 2 && !delta_in && !add_rows && s && s_rcp && !zpf &&
+        vq_rowquant_pair_smooth_fast((const half_t*)x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status,
+                                     (hipStream_t)stream))
+        return vq_check_launch();
     dim3 grid((n_tok + RQ_WAVES - 1) / RQ_WAVES);
     hipLaunchKernelGGL(rowquant_kernel, grid, dim3(RQ_THREADS), 0, (hipStream_t)stream, (const half_t*)x,
                        (const half_t*)add_rows, add_div > 0 ? add_div : 1, s, xq, sx, zx, R, zpf, delta_in, zp_in,
@@ -477,9 +484,9 @@ extern "C" int vq_ln_modulate_rowquant(const void* x, const float* shift, const 
     if (B == 1 && vq_lnq_fast((const half_t*)x, shift, scale, ln_eps, n_out, s, s_rcp, xq, sx, zx, R, (half_t*)xm_out, n_tok,
                               C, Kp, n_bits, status, (hipStream_t)stream))
         return vq_check_launch();
-    if (B == 2 && n_out == 1 && !(s && s[0]) && !xm_out &&
-        vq_lnq_pair_fast((const half_t*)x, shift, scale, ln_eps, xq[0], sx[0], zx[0], R[0], n_tok, C, Kp, n_bits, status,
-                         (hipStream_t)stream))
+    if (B == 2 && n_out == 1 && !xm_out &&
+        vq_lnq_pair_fast((const half_t*)x, shift, scale, ln_eps, s ? s[0] : nullptr, (s && s[0] && s_rcp) ? s_rcp[0] : nullptr,
+                         xq[0], sx[0], zx[0], R[0], n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
         return vq_check_launch();
     LnqOut o;
     for (int j = 0; j < 3; ++j) {

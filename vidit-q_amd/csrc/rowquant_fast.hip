@@ -194,7 +194,10 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
 // stages s and 1/s in LDS once and its waves walk rows grid-stride (next row's data requested before the current one
 // is processed).  Same arithmetic in the same order as rowquant_fast_kernel's reciprocal path: bit-identical outputs.
 // ---------------------------------------------------------------------------
-template <int MAXCH, bool GELU>
+// PAIR: x [2, n_tok, C], partner waves 2k / 2k + 1 take the two samples of a token and exchange min / max through LDS
+// (one workgroup barrier per walk step, parity-double-buffered slots; every wave of a workgroup runs the same number
+// of steps)
+template <int MAXCH, bool GELU, bool PAIR = false>
 __global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
     const half_t* __restrict__ x, const float* __restrict__ s, const float* __restrict__ s_rcp, int8_t* __restrict__ xq,
     float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R, int n_tok, int C, int Kp, int n_bits,
@@ -211,16 +214,25 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
     const float qmax = (float)((1 << n_bits) - 1);
     const int cx = (n_bits == 8) ? 128 : 0;
     const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
-    const int stride = gridDim.x * RQF_WAVES;
-    int tok = blockIdx.x * RQF_WAVES + (threadIdx.x >> 6);
+    const int wv = threadIdx.x >> 6;
+    const int stride = PAIR ? gridDim.x * (RQF_WAVES / 2) : gridDim.x * RQF_WAVES;
+    const int tok0 = PAIR ? blockIdx.x * (RQF_WAVES / 2) + (wv >> 1) : blockIdx.x * RQF_WAVES + wv;
+    const size_t roff = (PAIR && (wv & 1)) ? (size_t)n_tok : 0;   // row = token + roff
+    // walk steps: per wave, or (PAIR) per workgroup - the count of its first pair, the others idle through their tail
+    const int base = PAIR ? blockIdx.x * (RQF_WAVES / 2) : tok0;
+    const int n_it = base < n_tok ? (n_tok - base + stride - 1) / stride : 0;
+    __shared__ float pm[2][RQF_WAVES][2];
     half8 hn[MAXCH];
-    if (tok < n_tok) {
-        const half_t* row = x + (size_t)tok * C;
+    if (n_it > 0) {
+        const half_t* row = x + ((size_t)(tok0 < n_tok ? tok0 : n_tok - 1) + roff) * C;
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i)
             if (lane * 8 + i * 512 < C) hn[i] = *reinterpret_cast<const half8*>(row + lane * 8 + i * 512);
     }
-    for (; tok < n_tok; tok += stride) {
+    for (int it = 0; it < n_it; ++it) {
+        const int tk = tok0 + it * stride;
+        const bool live = tk < n_tok;
+        const size_t tok = (size_t)(live ? tk : n_tok - 1) + roff;
         float w[MAXCH][8];
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i)
@@ -228,8 +240,9 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) w[i][e] = GELU ? (float)(half_t)rq_gelu_tanh((float)hn[i][e]) : (float)hn[i][e];
             }
-        if (tok + stride < n_tok) {                        // next row in flight under this row's arithmetic
-            const half_t* row = x + (size_t)(tok + stride) * C;
+        if (it + 1 < n_it) {                               // next row in flight under this row's arithmetic
+            const int tn = tk + stride;
+            const half_t* row = x + ((size_t)(tn < n_tok ? tn : n_tok - 1) + roff) * C;
 #pragma unroll
             for (int i = 0; i < MAXCH; ++i)
                 if (lane * 8 + i * 512 < C) hn[i] = *reinterpret_cast<const half8*>(row + lane * 8 + i * 512);
@@ -254,13 +267,22 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
         }
         vmin = wave_min_f(vmin);
         vmax = wave_max_f(vmax);
+        if constexpr (PAIR) {
+            if (lane == 0) {
+                pm[it & 1][wv][0] = vmin;
+                pm[it & 1][wv][1] = vmax;
+            }
+            __syncthreads();
+            vmin = fminf(vmin, pm[it & 1][wv ^ 1][0]);
+            vmax = fmaxf(vmax, pm[it & 1][wv ^ 1][1]);
+        }
         float delta, zp;
         bool small;
         vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
-        if (small && lane == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
+        if (small && lane == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
         const float inv = __fdiv_rn(1.0f, delta);
         const int izx = (int)zp - cx;
-        int8_t* qrow = xq + (size_t)tok * Kp;
+        int8_t* qrow = xq + tok * Kp;
         uint32_t csum = 0;
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
@@ -268,13 +290,13 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
             if (c0 < C) {
                 uint2 p;
                 csum += rq_quant8(w[i], inv, delta, zp, qmax, flip, p);
-                *reinterpret_cast<uint2*>(qrow + c0) = p;
+                if (live) *reinterpret_cast<uint2*>(qrow + c0) = p;
             } else if (c0 < Kp) {
-                *reinterpret_cast<uint2*>(qrow + c0) = make_uint2(0u, 0u);
+                if (live) *reinterpret_cast<uint2*>(qrow + c0) = make_uint2(0u, 0u);
             }
         }
         const int rs = wave_sum_i((int)csum) - cx * C;
-        if (lane == 0) {
+        if (lane == 0 && live) {
             sx[tok] = delta;
             zx[tok] = izx;
             R[tok] = rs - C * izx;
@@ -282,16 +304,17 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
     }
 }
 
-template <bool GELU>
+template <bool GELU, bool PAIR = false>
 static bool launch_rq_smooth_lds(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
                                  int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
     if (C % 8 != 0 || C <= 1536 || C > 4608) return false;
     const int lds = 2 * C * (int)sizeof(float);
-    auto k = rowquant_smooth_lds_kernel<9, GELU>;
+    auto k = rowquant_smooth_lds_kernel<9, GELU, PAIR>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               2 * 4608 * (int)sizeof(float));
     if (e != hipSuccess) return false;
-    int grid = (n_tok + RQF_WAVES - 1) / RQF_WAVES;
+    constexpr int PER = PAIR ? RQF_WAVES / 2 : RQF_WAVES;  // tokens per workgroup and walk step
+    int grid = (n_tok + PER - 1) / PER;
     if (grid > 1024) grid = 1024;                          // 4 workgroups of 36.9 KB LDS per CU; rows grid-stride
     hipLaunchKernelGGL(k, dim3(grid), dim3(RQF_THREADS), lds, st, x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status);
     return true;
@@ -645,7 +668,7 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
 //     row (L2 / MALL hits: the activation is 38 MB) and redo the cheap LN, instead of one wave carrying 3 x 72 extra
 //     registers.  Output 0 also writes the modulated activation when asked for.
 // ---------------------------------------------------------------------------
-template <int NIT, bool LN, int RPW>
+template <int NIT, bool LN, int RPW, bool PAIR = false>   // PAIR: the wave's two rows are ONE token of a batch of two (see rowquant_half_kernel)
 __global__ __launch_bounds__(RQF_THREADS) void smooth_rowquant_half_kernel(
     const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
     LnqFastOut o, half_t* __restrict__ xm_out, int n_tok, int n_bits, int32_t* status) {
@@ -666,34 +689,40 @@ __global__ __launch_bounds__(RQF_THREADS) void smooth_rowquant_half_kernel(
         s4[i] = *reinterpret_cast<const float4v*>(sp + i * 128 + hl * 4);
         r4[i] = *reinterpret_cast<const float4v*>(rp + i * 128 + hl * 4);
         if constexpr (LN) {
-            sc4[i] = *reinterpret_cast<const float4v*>(scale + i * 128 + hl * 4);
-            sh4[i] = *reinterpret_cast<const float4v*>(shift + i * 128 + hl * 4);
+            const int bo = (PAIR && hi) ? C : 0;           // modulation vectors of the upper half's sample
+            sc4[i] = *reinterpret_cast<const float4v*>(scale + bo + i * 128 + hl * 4);
+            sh4[i] = *reinterpret_cast<const float4v*>(shift + bo + i * 128 + hl * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) sc4[i][e] = 1.0f + sc4[i][e];
         }
     }
     const int pair0 = (blockIdx.x * RQF_WAVES + (threadIdx.x >> 6)) * RPW;
+    // row of this half-wave in walk step p: two consecutive rows, or (PAIR) the two samples of token p
+    auto row_of = [&](int p) {
+        if constexpr (PAIR) return (p < n_tok ? p : n_tok - 1) + (hi ? n_tok : 0);
+        else {
+            const int t = p * 2 + (hi ? 1 : 0);
+            return t < n_tok ? t : n_tok - 1;
+        }
+    };
     half4 hn[NIT];
     {
-        int t = pair0 * 2 + (hi ? 1 : 0);
-        t = t < n_tok ? t : n_tok - 1;
+        const int t = row_of(pair0);
         const half_t* row = x + (size_t)t * C + hl * 4;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) hn[i] = *reinterpret_cast<const half4*>(row + i * 128);
     }
     for (int it = 0; it < RPW; ++it) {
-        if ((pair0 + it) * 2 >= n_tok) break;              // wave-uniform
-        int tok = (pair0 + it) * 2 + (hi ? 1 : 0);
-        const bool live = tok < n_tok;
-        if (!live) tok = n_tok - 1;                        // odd tail: the upper half re-does the last row, writes nothing
+        if ((PAIR ? pair0 + it : (pair0 + it) * 2) >= n_tok) break;   // wave-uniform
+        const bool live = PAIR || (pair0 + it) * 2 + (hi ? 1 : 0) < n_tok;
+        const int tok = row_of(pair0 + it);                // odd tail: the upper half re-does the last row, writes nothing
         float w[NIT][4];
 #pragma unroll
         for (int i = 0; i < NIT; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[i][e] = (float)hn[i][e];
         if (it + 1 < RPW) {                                // next pair's rows fly under this pair's arithmetic
-            int t = (pair0 + it + 1) * 2 + (hi ? 1 : 0);
-            t = t < n_tok ? t : n_tok - 1;
+            const int t = row_of(pair0 + it + 1);
             const half_t* row = x + (size_t)t * C + hl * 4;
 #pragma unroll
             for (int i = 0; i < NIT; ++i) hn[i] = *reinterpret_cast<const half4*>(row + i * 128);
@@ -740,6 +769,10 @@ __global__ __launch_bounds__(RQF_THREADS) void smooth_rowquant_half_kernel(
             }
         RQH_REDUCE2(float, fminf, vmin)
         RQH_REDUCE2(float, fmaxf, vmax)
+        if constexpr (PAIR) {                              // one grid for the token's two samples
+            vmin = fminf(vmin, __shfl_xor(vmin, 32));
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+        }
         float delta, zp;
         bool small;
         vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
@@ -770,12 +803,13 @@ __global__ __launch_bounds__(RQF_THREADS) void smooth_rowquant_half_kernel(
     }
 }
 
-template <bool LN, int RPW>
+template <bool LN, int RPW, bool PAIR = false>
 static bool launch_smooth_half(const half_t* x, const float* shift, const float* scale, float eps, const LnqFastOut& o,
                                int n_out, half_t* xm, int n_tok, int C, int n_bits, int32_t* status, hipStream_t st) {
-    dim3 grid((n_tok + 2 * RQF_WAVES * RPW - 1) / (2 * RQF_WAVES * RPW), n_out);
+    constexpr int PER = (PAIR ? 1 : 2) * RQF_WAVES * RPW;   // rows (PAIR: tokens) per workgroup
+    dim3 grid((n_tok + PER - 1) / PER, n_out);
 #define SMH_GO(N_)                                                                                                  \
-    hipLaunchKernelGGL((smooth_rowquant_half_kernel<N_, LN, RPW>), grid, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
+    hipLaunchKernelGGL((smooth_rowquant_half_kernel<N_, LN, RPW, PAIR>), grid, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
                        o, xm, n_tok, n_bits, status)
     switch (C / 128) {
         case 6: SMH_GO(6); break;
@@ -1030,9 +1064,27 @@ bool vq_rowquant_pair_fast(const half_t* x, int8_t* xq, float* sx, int32_t* zx, 
     return true;
 }
 
-bool vq_lnq_pair_fast(const half_t* x, const float* shift, const float* scale, float eps, int8_t* xq, float* sx,
+// the same with the smooth-quant division x / s (reciprocal form) in front of the quantizer
+bool vq_rowquant_pair_smooth_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
+                                  int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+    if (C > 1536)
+        return n_tok >= 2 && launch_rq_smooth_lds<false, true>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st);
+    if (C % 128 != 0 || Kp != C || C < 768 || C > 1280) return false;
+    LnqFastOut o{};
+    o.s[0] = s, o.r[0] = s_rcp, o.xq[0] = xq, o.sx[0] = sx, o.zx[0] = zx, o.R[0] = R;
+    return launch_smooth_half<false, 2, true>(x, nullptr, nullptr, 0.f, o, 1, nullptr, n_tok, C, n_bits, status, st);
+}
+
+bool vq_lnq_pair_fast(const half_t* x, const float* shift, const float* scale, float eps, const float* s, const float* s_rcp,
+                      int8_t* xq, float* sx,
                       int32_t* zx, int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
     if (Kp != C || !(C == 1152 || C == 1024 || C == 1280 || C == 768)) return false;
+    if (s) {
+        if (!s_rcp) return false;
+        LnqFastOut o{};
+        o.s[0] = s, o.r[0] = s_rcp, o.xq[0] = xq, o.sx[0] = sx, o.zx[0] = zx, o.R[0] = R;
+        return launch_smooth_half<true, 2, true>(x, shift, scale, eps, o, 1, nullptr, n_tok, C, n_bits, status, st);
+    }
     dim3 g2((n_tok + RQF_WAVES - 1) / RQF_WAVES);
 #define LNP_GO(N_)                                                                                                    \
     hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, true>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
