@@ -61,8 +61,9 @@ cal_copy_f = cal_copy_f[0] if cal_copy_f else float("nan")
 
 
 def short(k):
-    for a, b in (("gemm_i8_wide_kernel<256, 288, 4, 2, 0", "GEMM epi none (qkv x2, cross-q, fc1, kv)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 1", "GEMM fc1 + GELU epilogue"),
+    for a, b in (("gemm_i8_wide_kernel<256, 288, 4, 2, 0", "GEMM epi none (qkv x2, cross-q, fc1)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 1", "GEMM fc1 + GELU epilogue"),
                  ("gemm_i8_wide_kernel<256, 288, 4, 2, 2", "GEMM + gate*y + resid (proj x2, fc2)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 3", "GEMM + resid (cross proj)"),
+                 ("gemm_i8_wide_kernel<128, 288, 4, 2, 0", "GEMM 128-row tiles (prompt K/V of all 28 blocks, one launch)"),
                  ("attn_fwd32d_kernel", "spatial attention (flash, 1024 keys)"), ("attn_fwd8_kernel", "spatial attention, previous generation"), ("attn_temporal_quant", "temporal attention + proj quantizer"),
                  ("attn_cross_reg", "cross attention (K/V^T in registers)"), ("ln_modulate_rowquant_half", "LN + modulate + quantizer C=1152"),
                  ("rowquant_half", "per-token quantizer C=1152"), ("rowquant_fast_kernelILi9", "per-token quantizer C=4608")):
@@ -74,9 +75,9 @@ def short(k):
 # algorithmic work per launch at 16 x 512 x 512: bytes moved once, ops
 ALG = {
     "GEMM fc1 + GELU epilogue": (M * 1152 + 4608 * 1152 + 2 * M * 4608, 2.0 * M * 4608 * 1152, "i8"),
-    # launch-weighted means over the launches of one block-sample (the few batched prompt-kv launches are ignored):
+    # launch-weighted means over the launches of one block-sample:
     # qkv x 2 (N 3456) + cross-q (N 1152) + fc1 (N 4608, GELU in the next quantizer since round 3), all K = 1152
-    "GEMM epi none (qkv x2, cross-q, fc1, kv)": ((2 * (M * 1152 + 3456 * 1152 + 2 * M * 3456) + (M * 1152 + 1152 * 1152 + 2 * M * 1152)
+    "GEMM epi none (qkv x2, cross-q, fc1)": ((2 * (M * 1152 + 3456 * 1152 + 2 * M * 3456) + (M * 1152 + 1152 * 1152 + 2 * M * 1152)
                                                    + (M * 1152 + 4608 * 1152 + 2 * M * 4608)) / 4,
                                                   2.0 * M * 1152 * (2 * 3456 + 1152 + 4608) / 4, "i8"),
     # proj x 2 (N = K = 1152) + fc2 (N 1152, K 4608), each reading the residual as well
