@@ -310,6 +310,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    # VQ_BENCH_REHEARSAL=1: the N > 1 control flow on a box with fewer devices than ranks (ranks share devices, gloo
+    # instead of RCCL, which refuses two ranks on one device) - a dry run of the launch line, never a measurement
+    rehearsal = os.environ.get("VQ_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import viditq_amd  # noqa: F401
@@ -319,7 +324,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if a.gemm_variant is not None:
         ops.DEFAULT_GEMM_VARIANT = a.gemm_variant
 
@@ -375,6 +383,8 @@ def main():
                 "whole_step_int8_frac": 43.87e12 * (a.depth / 28.0) * value / world / PEAK_INT8,
                 "roofline": head["roofline"],
                 "extras": extras}
+        if rehearsal:
+            line["rehearsal"] = "ranks share devices, gloo backend: control-flow dry run, NOT a measurement"
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
