@@ -315,16 +315,6 @@ class QuantLayer(nn.Module):
         self._packed[key] = (deq, wq.delta, self.weight._version, s)
         return deq
 
-    def exact_fill_linear(self, x3: torch.Tensor, r: int = 0, s: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """This Linear as the reference's fp16 mode computes it INCLUDING the global eps fill of its dynamic per-token
-        quantizer (base_quantizer.py:219-223: one token with step < 1e-6 sets EVERY token's step to 1e-6):
-        vq_fakequant_act reproduces the fill on the device, the contraction is a plain fp16 GEMM.  For the few-row
-        inputs that are not normalised (prompt tokens into cross_attn.kv_linear); no host synchronisation."""
-        x = x3 if s is None else (x3.float() / s).to(x3.dtype)
-        xh, _, _, _ = ops.fakequant_act(x.contiguous(), n_bits=self.act_quantizer.n_bits)
-        b = self.bias
-        return F.linear(xh, self.dequantized_weight_f16(r, s), None if b is None else b.detach().half())
-
     # With weight_quant off and smooth_quant on, QuantLayer multiplies the FP weight by the smoothing vector
     # (quant_layer.py:188-189: (x/s)(W*s)^T = x W^T); the STDiT attention subclasses do NOT
     # (stdit_quant_layer.py:90,181,298: (x/s) W^T) - kept as released, see fp_weight_smoothed there.
