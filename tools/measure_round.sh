@@ -20,9 +20,11 @@ pass() {  # name, counters...
 }
 pass FETCH_SIZE FETCH_SIZE
 pass WRITE_SIZE WRITE_SIZE
+if [ -z "$VQ_MEASURE_SKIP_SQ" ]; then   # the SQ / GRBM sets only change when the GEMM kernel does (summary keeps the previous file otherwise)
 pass SQ1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS
 pass SQ2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU
 pass GRBM GRBM_GUI_ACTIVE GRBM_COUNT
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 100 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/cal_$c -o p -- python $R/tools/traffic_cal.py > $O/cal_$c.log 2>&1)
 done

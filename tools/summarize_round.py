@@ -147,6 +147,8 @@ open(os.path.join(P, TAG + "_hbm_traffic.md"), "w").write("\n".join(lines) + "\n
 
 # ---- SQ / GRBM counters of the GEMM kernels
 S1, S2, G = counters("SQ1"), counters("SQ2"), counters("GRBM")
+if not S1:
+    sys.exit(0)
 lines = ["# Round %s - " % RND + "PMC counters of the SHIPPING GEMM kernels inside the bench (gemm_i8_wide_kernel<256,288,4,2,EPI>)", "",
          "`rocprofv3 --pmc <one set per pass> --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-graph ...` (depth 28).  SQ counters",
          "are summed over all waves of a dispatch; SQ_*_CYCLES in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles; 16 per",

@@ -96,9 +96,11 @@ class DPMSolverPP:
             return self.model(x, torch.full((n,), t_val, dtype=torch.float32, device=x.device), self.condition,
                               **self.model_kwargs)
         x2 = torch.cat([x, x])
-        if self._c2 is None or self._c2[0] is not self.condition or self._c2[1] is not self.uncondition:
-            self._c2 = (self.condition, self.uncondition, torch.cat([self.uncondition, self.condition]))
-        out = self.model(x2, torch.full((2 * n,), t_val, dtype=torch.float32, device=x.device), self._c2[2],
+        c, u = self.condition, self.uncondition
+        hit = self._c2
+        if hit is None or hit[0][0] is not c or hit[0][2] is not u or hit[0][1] != c._version or hit[0][3] != u._version:
+            self._c2 = ((c, c._version, u, u._version), torch.cat([u, c]))
+        out = self.model(x2, torch.full((2 * n,), t_val, dtype=torch.float32, device=x.device), self._c2[1],
                          **self.model_kwargs)
         noise_uncond, noise = out.chunk(2)
         return noise_uncond + self.cfg_scale * (noise - noise_uncond)
