@@ -311,3 +311,56 @@ def test_bench_refuses_stale_gemm_traffic(tmp_path, monkeypatch):
     assert t is None and "STALE" in why
     (fake / "profiles" / "r09_gemm_traffic.json").write_text(json.dumps({"hbm_bytes_per_launch": 1.0, "source": "s"}))
     assert bench.gemm_traffic()[0] is None               # no hash recorded: refused as well
+
+
+def test_dpm_solver_model_input_time_is_the_reference_expression():
+    """The t2i loop hands the model (t_continuous - 1 / N) * 1000 (dpm_solver model_wrapper, noise-prediction branch), a
+    float32 tensor expression in the reference.  Here it is computed on the host and materialised by a fill (no
+    host-to-device copy, hence no per-step synchronisation): the values must be the same float32 numbers for every step
+    of the schedule, the (uncond | cond) embedding is concatenated once and follows in-place edits of its parts."""
+    import viditq_amd  # noqa: F401
+    from viditq_amd.t2i.dpm_solver import DPMS_sigma
+    seen = []
+
+    def model(x, t, y, **kw):
+        seen.append((t.clone(), y.clone()))
+        return x * 0.1
+
+    cond, unc = torch.ones(1, 1, 3, 4), torch.zeros(1, 1, 3, 4)
+    s = DPMS_sigma(model, condition=cond, uncondition=unc, cfg_scale=4.5)
+    steps = 20
+    s.sample(torch.randn(1, 4, 8, 8), steps=steps, order=2)
+    ts = torch.linspace(s.ns.T, 1.0 / s.ns.total_N, steps + 1)
+    assert len(seen) == steps
+    for (t, y), tc in zip(seen, ts[:steps]):
+        ref = (tc - 1.0 / s.ns.total_N) * 1000.0                  # the reference's tensor expression, float32
+        assert t.dtype == torch.float32 and t.shape == (2,) and torch.equal(t, ref.expand(2))
+        assert torch.equal(y, torch.cat([unc, cond]))
+    cat0 = s._c2[1]
+    s.sample(torch.randn(1, 4, 8, 8), steps=2, order=2)
+    assert s._c2[1] is cat0                                        # same tensors, same versions: concatenated once
+    cond.mul_(2.0)                                                 # an in-place edit must not be served from the cache
+    seen.clear()
+    s.sample(torch.randn(1, 4, 8, 8), steps=2, order=2)
+    assert torch.equal(seen[0][1], torch.cat([unc, cond]))
+
+
+def test_graphed_model_falls_through_without_a_gpu_and_keys_on_argument_identity():
+    import viditq_amd  # noqa: F401
+    from viditq_amd.graph import GraphedModel, _ident
+    calls = []
+    gm = GraphedModel(lambda x, t, y, **kw: calls.append(kw) or x + 1)
+    x = torch.zeros(2, 3)
+    assert torch.equal(gm(x, torch.zeros(2), torch.zeros(2, 4), mask=None), x + 1) and len(gm.graphs) == 0
+    m = torch.ones(1, 5, dtype=torch.int64)
+    k0 = _ident(dict(mask=m, data_info=None))
+    assert k0 == _ident(dict(data_info=None, mask=m))
+    m[0, 0] = 0                                                    # content changed in place: another key
+    assert _ident(dict(mask=m, data_info=None)) != k0
+    assert _ident(dict(mask=m.clone(), data_info=None)) != _ident(dict(mask=m, data_info=None))
+
+    class L(torch.nn.Module):
+        smooth_quant_running_stat = True
+        channel_wise_scale_type = "momentum_act_max"
+    assert GraphedModel(lambda *a, **k: None, qnn=torch.nn.Sequential(L()))._host_visible_state()
+    assert not GraphedModel(lambda *a, **k: None, qnn=torch.nn.Sequential(torch.nn.Linear(2, 2)))._host_visible_state()
