@@ -261,7 +261,8 @@ def test_gemm_epilogues(ops, dev):
 
 
 @pytest.mark.parametrize("w_bits", [8, 4])
-@pytest.mark.parametrize("M,N,K", [(8192, 1152, 1152), (1024, 1152, 4608), (300, 2304, 1152), (391, 580, 256)])
+@pytest.mark.parametrize("M,N,K", [(8192, 1152, 1152), (1024, 1152, 4608), (300, 2304, 1152), (391, 580, 256),
+                                   (200, 96, 256), (8192, 1152, 4608), (2048, 1152, 2048)])   # even k-tile counts: the parked parameter block
 def test_gemm_half_height_tile_is_bit_identical(ops, dev, M, N, K, w_bits):
     """The 128 x 288 form of the ring kernel (variant 16: what the library picks when all its tiles fit one round of the
     256 CUs - PixArt-Sigma's N = 1152 Linears at M = 8192, prompt K/V) computes every output element with the arithmetic

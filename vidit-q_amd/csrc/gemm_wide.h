@@ -233,7 +233,18 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
 #undef VQ_WIDE_STEP
     if (ts) ts[2] = __builtin_readcyclecounter();
     const float* gate_row = EPI == VQ_EPI_GATE_RESID ? ring_tile_gate_row<BM>(a, m0) : nullptr;
-    ring_stage_params<BM, BN, WAVES_M, WAVES_N>(a, smem, m0, n0, tid, gate_row);
+    // The dequantisation parameters are parked behind the epilogue slabs.  For the 256-row tile (and for W4 stages) that
+    // is past the end of the ring, so they can be written while slower waves still read fragments; for the 128-row
+    // tile with 128-byte weight rows the block lies INSIDE stage 1 - the stage the last k-tile occupies when their
+    // number is even (K = 256, 4608): parked before every wave had left the loop it overwrote weight rows under the
+    // last MFMAs (wrong columns in rows of the slower waves; found by test_gemm_low_bit_weights).  There the global
+    // loads are issued first and the LDS writes wait for a workgroup barrier.
+    constexpr bool PAR_IN_RING = NW * WTM * (WTN * 2 + 16) < 2 * STAGE;
+    const ColParams colp = ring_load_col_params<BN>(a, n0, tid, gate_row);
+    const RowParams rowp = ring_load_row_params<BM>(a, m0, tid);
+    if constexpr (PAR_IN_RING) __syncthreads();
+    ring_park_col_params<BM, BN, WAVES_M, WAVES_N>(colp, smem, tid);
+    ring_park_row_params<BM, BN, WAVES_M, WAVES_N>(rowp, smem, tid);
     __syncthreads();
     ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts, tid, gate_row != nullptr);
 }
