@@ -47,7 +47,31 @@ def parse():
     ap.add_argument("--gemm-variant", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region (no HIP graph)")
     ap.add_argument("--one-stream", action="store_true", help="cond and uncond serialised on one stream")
+    ap.add_argument("--prompts", type=int, default=None,
+                    help="BASELINE config 4: P prompts sharded round-robin over the ranks (prompt i -> rank i mod N, 64 over "
+                         "8 GPUs = 8 per rank), each prompt with its own captured graph, W warm-up + K timed steps per "
+                         "prompt; default: one prompt per GPU")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks ourselves,
+    through the same `torch.distributed.run` line the contract names, and exit with its status.  A box with fewer devices
+    than ranks is an ERROR (never a silent one-rank run that prints n_gpus 1) unless VQ_BENCH_REHEARSAL=1."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < a.gpus and os.environ.get("VQ_BENCH_REHEARSAL") != "1":
+        sys.exit("bench.py: --gpus %d asked for, %d device(s) visible - refusing to run (VQ_BENCH_REHEARSAL=1 shares "
+                 "devices between ranks over gloo as a control-flow dry run)" % (a.gpus, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(depth_total=28):
@@ -95,10 +119,12 @@ def gemm_traffic():
     profiles/r0N_gemm_traffic.json) is reported - and REFUSED (traffic null + a reason) when any GEMM source is newer
     than the measurement, so a kernel change can never ship stale bytes."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_gemm_traffic.json")))
+    import re
+    cands = [(int(m.group(1)), f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json"))
+             for m in [re.match(r"r(\d+)_gemm_traffic\.json$", os.path.basename(f))] if m]
     if not cands:
-        return None, "no profiles/r0N_gemm_traffic.json"
-    tj = cands[-1]
+        return None, "no profiles/rNN_gemm_traffic.json"
+    tj = max(cands)[1]                                  # the latest ROUND (numeric: r10 follows r09)
     with open(tj) as f:
         t_ = json.load(f)
     import hashlib
@@ -137,7 +163,10 @@ def stdit_legs(a, dev, rank, world, plans, steps, warmup, dist=None, events=True
     out = []
     with torch.no_grad():
         model = synth.build_stdit(dev, depth=a.depth)
-        qnn = shard.quantize_and_distribute(model, cfg, rank, world)     # rank 0 calibrates + packs, RCCL broadcast
+        # a plan that switches bit widths per step range names them up front: they travel in the one broadcast, and
+        # ranks > 0 (which drop their fp16 master weights) never have to re-pack
+        mp_w = synth.synthetic_mp_config(model, 20)[0] if "w4a8_mp" in plans else None
+        qnn = shard.quantize_and_distribute(model, cfg, rank, world, mp_weight_cfg=mp_w)   # rank 0 calibrates + packs, RCCL broadcast
         assert all(b.fused_ok() for b in qnn.model.blocks), "hot path must be the fused HIP route"
         for plan in plans:
             res = _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, events, hoisted)
@@ -160,17 +189,20 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
         from viditq_amd.t2v.iddpm import TimestepMP
         ptq.enable_timestep_wise_mp(qnn, *synth.synthetic_mp_config(qnn, n_sampling))
         mp = TimestepMP(qnn)
-    # one prompt per GPU in flight; prompt index = rank (prompt i -> rank i mod R)
-    embeds, lens = synth.synthetic_prompts(world, dev)
-    x = synth.synthetic_latent(rank, device=dev).float()
-    y = embeds["y"][rank:rank + 1]                                   # [1, 2, 1, 120, 4096]
-    y = y.permute(1, 0, 2, 3, 4).reshape(2, 1, 120, 4096)
-    mask = embeds["mask"][rank:rank + 1]
-    y_c, y_u = y[:1], y[1:]
+    # prompt i -> rank i mod R; default one prompt per GPU (prompt index = rank), --prompts P: P prompts round-robin
+    from viditq_amd import shard
+    n_prompts = a.prompts if a.prompts else world
+    mine = shard.prompts_of_rank(n_prompts, rank, world)
+    assert mine, "rank %d has no prompt (%d prompts over %d ranks)" % (rank, n_prompts, world)
+    embeds, lens = synth.synthetic_prompts(n_prompts, dev)
     idx = list(range(sch.num_timesteps))[::-1]
-    buf = torch.empty_like(x)
+    gs = None
 
-    gs = None if a.no_graph else graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
+    def inputs(pi):
+        x = synth.synthetic_latent(pi, device=dev).float()
+        y = embeds["y"][pi:pi + 1]                                   # [1, 2, 1, 120, 4096]
+        y = y.permute(1, 0, 2, 3, 4).reshape(2, 1, 120, 4096)
+        return x, torch.empty_like(x), y[:1], y[1:], embeds["mask"][pi:pi + 1]
 
     def step(j, x, buf, eager=False):
         i = idx[j % len(idx)]
@@ -185,28 +217,36 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
         out = sch.ddim_step(x, cond, unc, i, sch.cfg_scale, 0.0, out=buf)
         return out, x
 
-    if mp is not None:                              # pack + capture every mixed-precision key up front
-        for i in idx[::max(1, len(idx) // 4)]:
-            key = mp.apply(i)
-            if gs is not None:
-                gs.forward_pair(x, sch.timestep_map[i], key)
-    elif gs is not None and synth.uses_smooth_quant(cfg):   # one graph per smooth-quant time-range
-        for t_probe in (999, 0):
-            gs.forward_pair(x, t_probe, None)
-    for j in range(warmup):
-        x, buf = step(j, x, buf)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for j in range(warmup, warmup + steps):
-        x, buf = step(j, x, buf)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    el = 0.0
+    for n_done, pi in enumerate(mine):
+        # a prompt's token selection is baked into its captured graphs: each prompt captures its own (untimed, as the
+        # reference's per-prompt set-up is), then runs W warm-up and K timed steps
+        x, buf, y_c, y_u, mask = inputs(pi)
+        gs = None if a.no_graph else graph.GraphedSampler(qnn, y_c, y_u, mask, two_streams=not a.one_stream)
+        if mp is not None:                              # pack + capture every mixed-precision key up front
+            for i in idx[::max(1, len(idx) // 4)]:
+                key = mp.apply(i)
+                if gs is not None:
+                    gs.forward_pair(x, sch.timestep_map[i], key)
+        elif gs is not None and synth.uses_smooth_quant(cfg):   # one graph per smooth-quant time-range
+            for t_probe in (999, 0):
+                gs.forward_pair(x, t_probe, None)
+        for j in range(warmup):
+            x, buf = step(j, x, buf)
+        torch.cuda.synchronize()
+        if dist is not None and n_done == 0:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(warmup, warmup + steps):
+            x, buf = step(j, x, buf)
+        torch.cuda.synchronize()
+        if dist is not None and n_done == len(mine) - 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        el += time.perf_counter() - t0
+        if n_done < len(mine) - 1:
+            gs = None                                   # frees this prompt's graphs before the next capture
     assert torch.isfinite(x).all()
     # live roofline: the SAME K steps once more, launched eagerly with a HIP-event pair around
     # every GEMM launch on the launch stream (events cannot be recorded inside a captured graph)
@@ -240,9 +280,9 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
                   "note": "prompt K/V + embedding computed once per prompt instead of once per forward; exact; not the headline"}
         gs = gs_keep
         qnn.model.set_prompt_cache(False)
-    del gs
-    res.update(el=el, steps=steps, n_sampling=n_sampling, cached=cached,
-           roofline=gemm_roofline(timing, el, plan == "w8a8") if timing else None)
+    gs = None
+    res.update(el=el, steps=steps * len(mine), n_sampling=n_sampling, cached=cached, n_prompts=n_prompts, prompts_here=len(mine),
+           roofline=gemm_roofline(timing, el / len(mine), plan == "w8a8") if timing else None)
     return res
 
 
@@ -304,15 +344,54 @@ def pixart_leg(dev, steps=4, w_bits=4, size=1024, Lp=300):
             "status_word": status, "gemm_frac_of_int8_peak": roof["frac"], "gemm_avg_launch_us": roof["avg_launch_us"]}
 
 
+def launch_only(a, rank, world):
+    """VQ_BENCH_LAUNCH_ONLY=1: the launch / rendezvous / gather / print skeleton of main() with no device work (gloo) -
+    what the CPU test of the plain-`python bench.py --gpus N` form runs."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    el_t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    per_rank = [float(el_t)]
+    if world > 1:
+        every = [torch.zeros_like(el_t) for _ in range(world)]
+        dist.all_gather(every, el_t)
+        per_rank = [float(t.item()) for t in every]
+    if rank == 0:
+        line = {"launch_only": True, "n_gpus": world, "per_rank_steps_per_s": [a.steps / t for t in per_rank]}
+        check_line(line, a)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def check_line(line, a):
+    """The line must describe the run that was asked for: one rate per rank, as many ranks as --gpus, and - for N > 1 -
+    a weight broadcast that moved bytes."""
+    assert line["n_gpus"] == a.gpus == len(line["per_rank_steps_per_s"]), \
+        "n_gpus %r, --gpus %r, %d per-rank rates" % (line["n_gpus"], a.gpus, len(line["per_rank_steps_per_s"]))
+    if a.gpus > 1 and not line.get("launch_only"):
+        wb = line.get("weights_broadcast")
+        assert wb and wb["bytes"] > 0, "N > 1 run without a weight broadcast: %r" % (wb,)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                                   # never returns
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or plain "
+                 "`python bench.py --gpus %d`, which starts its own ranks)" % (a.gpus, world, a.gpus, a.gpus))
     # VQ_BENCH_REHEARSAL=1: the N > 1 control flow on a box with fewer devices than ranks (ranks share devices, gloo
     # instead of RCCL, which refuses two ranks on one device) - a dry run of the launch line, never a measurement
     rehearsal = os.environ.get("VQ_BENCH_REHEARSAL") == "1"
+    if os.environ.get("VQ_BENCH_LAUNCH_ONLY") == "1":
+        return launch_only(a, rank, world)
+    if torch.cuda.device_count() < (world if not rehearsal else 1):
+        sys.exit("bench.py: %d rank(s) on this node, %d device(s) visible" % (world, torch.cuda.device_count()))
     if rehearsal:
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -343,7 +422,7 @@ def main():
     el_max = float(el_t.item())
 
     extras = None
-    if rank == 0 and world == 1 and a.plan == "w8a8" and not a.no_extras and a.depth == 28:
+    if rank == 0 and world == 1 and a.plan == "w8a8" and not a.no_extras and a.depth == 28 and not a.prompts:
         extras = {}
         legs = stdit_legs(a, dev, 0, 1, ["w4a8", "w4a8_mp"], 4, 2, events=not a.no_roofline_events, hoisted=False)
         for plan, r in zip(("w4a8", "w4a8_mp"), legs):
@@ -358,26 +437,31 @@ def main():
                           "(viditq_amd.synth); NOT the headline value")
 
     if rank == 0:
-        steps_total = a.steps * world
-        value = steps_total / el_max
+        from viditq_amd import shard
+        n_prompts = head["n_prompts"]
+        steps_of = [a.steps * len(shard.prompts_of_rank(n_prompts, r, world)) for r in range(world)]
+        value = sum(steps_of) / el_max
         plan_name = {"w8a8": "W8A8", "w4a8": "W4A8 (timestep-aware channel balancing)",
                      "w4a8_mp": "W4A8 mixed precision (per-layer bit widths)"}[a.plan]
         plan_yaml = {"w8a8": "w8a8_dynamic.yaml", "w4a8": "w4a8_timestep_aware_cb.yaml, synthetic calibration",
                      "w4a8_mp": "w4a8_timestep_aware_cb.yaml + t20 mixed-precision config, synthetic calibration"}[a.plan]
         line = {"metric": "denoising steps/sec (whole node), OpenSORA STDiT 16x512x512 " + plan_name, "value": value,
                 "unit": "denoising steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": el_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": el_max / max(steps_of) * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None,
                 "dtype": ("int8 (W8A8 Linear, int32 acc)" if a.plan == "w8a8" else "int8 x int4/int8 weights (W4A8 Linear, int32 acc)")
                          + " + fp16 attention/residual",
                 "data": "synthetic (random-init STDiT-XL/2 weights, N(0,1) latents, random text embeds)",
                 "config": {"workload": "OpenSORA STDiT-XL/2 16x512x512 %s (%s), 1 prompt per GPU, "
-                                       "DDIM-%d schedule, cfg 4.0, cfg_split, depth %d" % (plan_name, plan_yaml, head["n_sampling"], a.depth),
-                           "tokens": 16384, "prompts_in_flight": world, "sharding": "prompt -> rank (no in-step collective)",
+                                       "DDIM-%d schedule, cfg 4.0, cfg_split, depth %d" % (plan_name, plan_yaml, head["n_sampling"], a.depth)
+                                       + ("" if not a.prompts else "; %d prompts round-robin over the ranks, per prompt: own graph "
+                                          "capture (untimed), %d warm-up + %d timed steps; time = sum of the timed regions"
+                                          % (n_prompts, a.warmup, a.steps)),
+                           "tokens": 16384, "prompts_in_flight": world, "prompts": n_prompts, "sharding": "prompt -> rank (no in-step collective)",
                            "status_word": head["status"], "hip_graph": not a.no_graph,
                            "cond_uncond_streams": 1 if (a.one_stream or a.no_graph) else 2},
                 # self-diagnosis of a multi-GPU run: every rank's own rate, and what the one set-up collective moved
-                "per_rank_steps_per_s": [a.steps / t for t in per_rank],
+                "per_rank_steps_per_s": [k / t for k, t in zip(steps_of, per_rank)],
                 "weights_broadcast": head["broadcast"],
                 "prompt_invariants_hoisted": head["cached"],
                 "whole_step_int8_frac": 43.87e12 * (a.depth / 28.0) * value / world / PEAK_INT8,
@@ -387,6 +471,7 @@ def main():
             line["rehearsal"] = "ranks share devices, gloo backend: control-flow dry run, NOT a measurement"
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        check_line(line, a)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

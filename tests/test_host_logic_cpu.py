@@ -359,8 +359,22 @@ def test_graphed_model_falls_through_without_a_gpu_and_keys_on_argument_identity
     assert _ident(dict(mask=m, data_info=None)) != k0
     assert _ident(dict(mask=m.clone(), data_info=None)) != _ident(dict(mask=m, data_info=None))
 
-    class L(torch.nn.Module):
-        smooth_quant_running_stat = True
-        channel_wise_scale_type = "momentum_act_max"
-    assert GraphedModel(lambda *a, **k: None, qnn=torch.nn.Sequential(L()))._host_visible_state()
-    assert not GraphedModel(lambda *a, **k: None, qnn=torch.nn.Sequential(torch.nn.Linear(2, 2)))._host_visible_state()
+    # the graph key covers everything that changes which kernels a forward launches (round-3 advisor finding: a bit-width
+    # or FP toggle between calls used to replay the OLD forward): one pass over the cached QuantLayer list per call
+    qnn = _tiny_qnn()
+    qnn.set_quant_state(True, True)
+    gm = GraphedModel(lambda *a, **k: None, qnn=qnn)
+    f0, r0, run0 = gm._state(None)
+    assert not run0 and r0 == 0 and len(gm._layers()) > 0 and gm._layers() is gm._layers()
+    layer = gm._layers()[0]
+    layer.weight_quantizer.bitwidth_refactor(4)
+    f1 = gm._state(None)[0]
+    assert f1 != f0
+    layer.weight_quantizer.bitwidth_refactor(8)
+    assert gm._state(None)[0] == f0                                # back to the first state: its graph is found again
+    layer.set_quant_state(False, False)
+    assert gm._state(None)[0] not in (f0, f1)
+    layer.set_quant_state(True, True)
+    layer.smooth_quant_running_stat, layer.channel_wise_scale_type = True, "momentum_act_max"
+    assert gm._state(None)[2]                                      # host-visible running statistic: not capturable
+    assert GraphedModel(lambda *a, **k: None, qnn=torch.nn.Sequential(torch.nn.Linear(2, 2)))._state(None) == (hash(()), 0, False)

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libviditq_hip.so")
+# VIDITQ_LIB=<path>: bind ANOTHER build of the same C ABI (smoke() checks a library it just built from source on the GPU
+# box in a child process this way); the default is the in-tree library
+LIB_PATH = os.environ.get("VIDITQ_LIB") or os.path.join(_HERE, "csrc", "libviditq_hip.so")
 
 VQ_OK = 0
 VQ_ST_EPSFILL = 1

@@ -149,7 +149,7 @@ class GraphedModel:
     """``model(x, t, y, **kwargs)`` for a sampling loop that calls one forward per step with the same shapes and the same
     keyword arguments (the t2i DPM-Solver loop, quant_txt2img.py:130-153: ``DPMS_sigma(GraphedModel(qnn.forward_with_dpmsolver),
     ...)``).  The ~540 launches of a PixArt forward are captured once per (shapes, keyword identities, smooth-quant
-    time-range, pack epoch) and replayed with the new latent / timestep / text embedding copied into the static inputs;
+    time-range, per-layer quant state and bit widths, pack epoch) and replayed with the new latent / timestep / text embedding copied into the static inputs;
     the result is a fresh tensor each call (multistep solvers keep earlier outputs).  Bit-identical to eager launches
     (tested).  At PixArt-Sigma 1024 x 1024 a forward is 19.9 ms of GPU work either way (50.3 steps/s eager, 49.7
     replayed): eager Python launches need 10.9 ms of host time per step and stay ahead of the GPU, a replay needs 3.0 ms;
@@ -161,40 +161,51 @@ class GraphedModel:
         self.graphs: Dict[Hashable, ForwardGraph] = {}
         self.max_graphs = max_graphs
         self._epoch = None
+        self._qlayers = None
 
-    def _range_of(self, t_id) -> int:
-        """Smooth-quant time-range the forward will run in: from ``timestep_id`` when the call passes one
-        (QuantModel.forward), else from the state the script set on the layers (set_timestep_id_for_quantlayer)."""
-        root = self.qnn
-        if root is None or not hasattr(root, "modules"):
-            return 0
+    def _layers(self):
+        """The QuantLayers under the wrapped model, collected once (wrapping happens before the loop; the module tree
+        does not change afterwards)."""
+        if self._qlayers is None:
+            root = self.qnn
+            from .qdiff.models.quant_layer import QuantLayer
+            self._qlayers = [m for m in root.modules() if isinstance(m, QuantLayer)] \
+                if root is not None and hasattr(root, "modules") else []
+        return self._qlayers
+
+    def _state(self, t_id):
+        """ONE pass over the cached layer list per call: (fingerprint of everything that changes which kernels a forward
+        launches - per-layer quant state, weight / activation bit widths, smooth-quant switch -, the smooth-quant
+        time-range of the forward, whether some layer keeps host-visible running state).  The attributes are plain
+        Python fields that scripts also set directly (quant_txt2img.py:297-300), so they are read, not tracked."""
         from .qdiff.models.quant_layer import find_interval
-        for layer in root.modules():
-            if getattr(layer, "smooth_quant", False) and hasattr(layer, "timerange"):
-                if t_id is not None:
-                    return find_interval(layer.timerange, int(t_id))
-                return int(layer._range_and_alpha()[0])
-        return 0
-
-    def _host_visible_state(self) -> bool:
-        """A layer that keeps a RUNNING smooth-quant statistic at inference (the released t2i W4A8 plan leaves it on for
-        blocks.27.mlp.fc2, quant_txt2img.py:297-300) updates host-visible state in every forward: not capturable."""
-        root = self.qnn
-        if root is None or not hasattr(root, "modules"):
-            return False
-        return any(getattr(m, "smooth_quant_running_stat", False) and "momentum" in str(getattr(m, "channel_wise_scale_type", ""))
-                   for m in root.modules())
+        fp, rng, running = [], None, False
+        for m in self._layers():
+            sq = bool(getattr(m, "smooth_quant", False))
+            fp.append((m.weight_quant, m.act_quant, m.weight_quantizer.n_bits, m.act_quantizer.n_bits, sq))
+            if sq and rng is None and hasattr(m, "timerange"):
+                # from ``timestep_id`` when the call passes one (QuantModel.forward), else from the state the script set
+                # on the layers (set_timestep_id_for_quantlayer)
+                rng = find_interval(m.timerange, int(t_id)) if t_id is not None else int(m._range_and_alpha()[0])
+            if getattr(m, "smooth_quant_running_stat", False) and "momentum" in str(getattr(m, "channel_wise_scale_type", "")):
+                # a RUNNING smooth-quant statistic at inference (the released t2i W4A8 plan leaves it on for
+                # blocks.27.mlp.fc2, quant_txt2img.py:297-300) updates host-visible state in every forward: not capturable
+                running = True
+        return hash(tuple(fp)), rng or 0, running
 
     def __call__(self, x, t, y, **kwargs):
         from .qdiff.models.quant_layer import PACK_EPOCH
-        if not x.is_cuda or self._host_visible_state():
+        if not x.is_cuda:
+            return self.fn(x, t, y, **kwargs)
+        fingerprint, rng, running = self._state(kwargs.get("timestep_id"))
+        if running:
             return self.fn(x, t, y, **kwargs)
         if self._epoch != PACK_EPOCH[0]:
             self.graphs.clear()                          # captured graphs reference re-packed weight buffers
             self._epoch = PACK_EPOCH[0]
         kw = {k: v for k, v in kwargs.items() if k != "timestep_id"}
         key = (tuple(x.shape), str(x.dtype), tuple(t.shape), str(t.dtype), tuple(y.shape), str(y.dtype), _ident(kw),
-               self._range_of(kwargs.get("timestep_id")))
+               rng, fingerprint)
         g = self.graphs.get(key)
         if g is None:
             if len(self.graphs) >= self.max_graphs:

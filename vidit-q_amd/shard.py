@@ -53,10 +53,25 @@ def pack_blob(tensors: List[Tuple[str, torch.Tensor]], device) -> Tuple[list, to
     return meta, blob
 
 
+_DTYPES = {n: getattr(torch, n) for n in ("uint8", "int8", "int16", "int32", "int64", "float16", "bfloat16", "float32",
+                                          "float64", "bool")}
+
+
 def unpack_blob(meta: list, blob: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Zero-copy views; every record is checked against the payload it claims to describe (a corrupt or truncated layout
+    record raises here instead of producing views of the wrong bytes)."""
     out = {}
+    size = blob.numel()
     for name, dt, shape, off, nbytes in meta:
-        out[name] = blob[off:off + nbytes].view(getattr(torch, dt)).reshape(shape)   # zero-copy views
+        if dt not in _DTYPES:
+            raise RuntimeError("packed-weight arena: tensor %r has dtype %r" % (name, dt))
+        n_el = 1
+        for d in shape:
+            n_el *= int(d)
+        if off < 0 or nbytes < 0 or off + nbytes > size or n_el * _DTYPES[dt].itemsize != nbytes:
+            raise RuntimeError("packed-weight arena: record of %r (%s %r, offset %d, %d bytes) does not fit a payload of %d "
+                               "bytes" % (name, dt, tuple(shape), off, nbytes, size))
+        out[name] = blob[off:off + nbytes].view(_DTYPES[dt]).reshape(shape)
     return out
 
 
@@ -76,31 +91,70 @@ def _small_state(qnn: QuantModel) -> List[Tuple[str, torch.Tensor]]:
     return items
 
 
-def _pack_jobs(qnn: QuantModel):
-    """(layer name, layer, time-range id, representative timestep) of every packed weight the hot loop will ask for."""
+def mp_plan_of(qnn: QuantModel, mp_weight_cfg) -> Tuple[Dict[str, set], set]:
+    """What a timestep-wise mixed-precision weight config (``{"hi-lo": {"model.<layer>": bits}, ..., "fp_layers": {"hi-lo":
+    [patterns]}}``, quant_txt2video_mp.py:533-540, applied per step by iddpm.TimestepMP) can ask of each layer over a
+    whole trajectory: ({layer name: every bit width some range assigns it}, {layer names some range switches to FP}).
+    Names are relative to ``qnn.model`` as in :meth:`QuantModel.quant_layers`."""
+    from .qdiff.models.quant_model import pattern_in
+    bits: Dict[str, set] = {}
+    fp: set = set()
+    if not mp_weight_cfg:
+        return bits, fp
+    names = [n for n, _ in qnn.quant_layers()]
+    for key, table in mp_weight_cfg.items():
+        if key == "fp_layers":
+            for pats in table.values():
+                for n in names:        # the match set_layer_quant(quant_level="per_layer") performs on "model." + n
+                    if any(pattern_in("model." + n, p_) or pattern_in("model." + n, "model." + p_) for p_ in pats):
+                        fp.add(n)
+            continue
+        for full, b in table.items():
+            n = full[len("model."):] if full.startswith("model.") else full
+            bits.setdefault(n, set()).add(int(b))
+    return bits, fp
+
+
+def _pack_jobs(qnn: QuantModel, mp_weight_cfg=None):
+    """(layer name, layer, time-range id, representative timestep, n_bits) of every packed weight the hot loop will ask
+    for: the layer's current bit width, plus - with a mixed-precision config - every other packable width a step range
+    assigns it (the grid is the same for all of them: base_quantizer.py:126 / bitwidth_refactor widen the clamp only)."""
     jobs = []
+    extra, _ = mp_plan_of(qnn, mp_weight_cfg)
     for name, layer in qnn.quant_layers():
         if layer.weight_quant and layer.act_quant and layer._can_pack():
             n_r = len(layer.timerange) if getattr(layer, "smooth_quant", False) else 1
-            for r in range(n_r):
-                jobs.append((name, layer, r, layer.timerange[r][0] if n_r > 1 else None))
+            base = layer.weight_quantizer.n_bits
+            widths = [base] + sorted(b for b in extra.get(name, ()) if b != base and b <= 8)
+            for nb in widths:
+                for r in range(n_r):
+                    jobs.append((name, layer, r, layer.timerange[r][0] if n_r > 1 else None, nb))
     return jobs
 
 
-def _pack_one(layer: QuantLayer, r: int, t_id, out=None):
+def _pack_one(layer: QuantLayer, r: int, t_id, out=None, nb=None):
     saved = layer.cur_timestep_id
+    wq = layer.weight_quantizer
+    saved_bits = wq.n_bits
     if t_id is not None:
         layer.cur_timestep_id = t_id
-    rr, alpha = layer._range_and_alpha()
-    pw = layer.packed_weight(rr, layer.smooth_vector(rr, alpha), out=out)
-    layer.cur_timestep_id = saved
+    if nb is not None and nb != saved_bits:
+        wq.bitwidth_refactor(nb)
+    try:
+        rr, alpha = layer._range_and_alpha()
+        pw = layer.packed_weight(rr, layer.smooth_vector(rr, alpha), out=out)
+    finally:
+        if wq.n_bits != saved_bits:
+            wq.bitwidth_refactor(saved_bits)
+        layer.cur_timestep_id = saved
     return pw
 
 
-def prepack(qnn: QuantModel):
-    """Pack every quantized Linear for every time-range so nothing is packed inside the loop."""
-    for _, layer, r, t_id in _pack_jobs(qnn):
-        _pack_one(layer, r, t_id)
+def prepack(qnn: QuantModel, mp_weight_cfg=None):
+    """Pack every quantized Linear for every time-range (and every bit width of a mixed-precision config) so nothing
+    is packed inside the loop."""
+    for _, layer, r, t_id, nb in _pack_jobs(qnn, mp_weight_cfg):
+        _pack_one(layer, r, t_id, nb=nb)
 
 
 _MAGIC = 0x56514152454E41   # "VQARENA"
@@ -124,14 +178,16 @@ def _decode_meta(raw: torch.Tensor) -> list:
 
 def arena_views(arena: torch.Tensor):
     """(meta, {name: zero-copy view}) of a self-describing arena: [header | layout record | tensors]."""
+    if arena.numel() < _HDR_BYTES:
+        raise RuntimeError("not a packed-weight arena: %d bytes" % arena.numel())
     hdr = arena[:_HDR_BYTES].view(torch.int64).tolist()
-    if hdr[0] != _MAGIC or hdr[1] != 1 or hdr[3] != arena.numel():
-        raise RuntimeError("not a packed-weight arena: header %r, %d bytes" % (hdr, arena.numel()))
+    if hdr[0] != _MAGIC or hdr[1] != 1 or hdr[3] != arena.numel() or hdr[2] < 0 or _payload_base(hdr[2]) > arena.numel():
+        raise RuntimeError("not a packed-weight arena: bad header %r, %d bytes" % (hdr, arena.numel()))
     meta = _decode_meta(arena[_HDR_BYTES:_HDR_BYTES + hdr[2]])
     return meta, unpack_blob(meta, arena[_payload_base(hdr[2]):])
 
 
-def prepack_into_arena(qnn: QuantModel):
+def prepack_into_arena(qnn: QuantModel, mp_weight_cfg=None):
     """Like :func:`prepack`, but the packed codes and per-channel terms are written straight into ONE flat byte
     buffer - the buffer that is then broadcast as is.  Rank 0 therefore never holds a second copy of the ~0.75 GB of
     packed weights (W8A8 STDiT-XL/2); the small state (grids, act scales) is copied behind them.  The buffer describes
@@ -140,11 +196,10 @@ def prepack_into_arena(qnn: QuantModel):
     tensors - nothing else has to travel, and nothing is pickled.  Returns (meta, arena)."""
     from . import ops
     dev = next(qnn.model.parameters()).device
-    jobs = _pack_jobs(qnn)
+    jobs = _pack_jobs(qnn, mp_weight_cfg)
     specs = []                                            # (key, shape, dtype) in arena order
-    for name, layer, r, _ in jobs:
+    for name, layer, r, _, nb in jobs:
         N, K = layer.weight.shape
-        nb = layer.weight_quantizer.n_bits
         for f, (shape, dt) in zip(("wq", "sw", "zw", "cs"), ops.packed_shapes(N, K, nb)):
             specs.append(("%s|pw|%d|%d|%s" % (name, r, nb, f), tuple(shape), dt))
     small = _small_state(qnn)
@@ -156,10 +211,9 @@ def prepack_into_arena(qnn: QuantModel):
     arena[:_HDR_BYTES] = torch.tensor([_MAGIC, 1, len(rec), arena.numel()], dtype=torch.int64).view(torch.uint8).to(dev)
     arena[_HDR_BYTES:_HDR_BYTES + len(rec)] = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
     views = unpack_blob(meta, arena[base:])
-    for name, layer, r, t_id in jobs:
-        nb = layer.weight_quantizer.n_bits
+    for name, layer, r, t_id, nb in jobs:
         out = [views["%s|pw|%d|%d|%s" % (name, r, nb, f)] for f in ("wq", "sw", "zw", "cs")]
-        _pack_one(layer, r, t_id, out=out)
+        _pack_one(layer, r, t_id, out=out, nb=nb)
     for k, v in small:
         views[k].copy_(v)
     return meta, arena
@@ -185,7 +239,7 @@ def _install_quant_state(qnn: QuantModel, tensors: Dict[str, torch.Tensor]):
         layer.install_packed(r, pw)
 
 
-def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None, packed=None):
+def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None, packed=None, mp_weight_cfg=None):
     """Grids + packed weights from ``src`` to all ranks: the arena's own 32-byte header first (a fixed-size int64
     tensor - the receivers learn the size to allocate), then the arena as ONE message; the layout record sits inside
     it (:func:`prepack_into_arena`), so no Python object is pickled and nothing else travels.  ``packed`` = the
@@ -197,14 +251,14 @@ def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None, 
     hdr = torch.zeros(_HDR_WORDS, dtype=torch.int64, device=dev)
     arena = None
     if rank == src:
-        _, arena = packed if packed is not None else prepack_into_arena(qnn)
+        _, arena = packed if packed is not None else prepack_into_arena(qnn, mp_weight_cfg)
         hdr.copy_(arena[:_HDR_BYTES].view(torch.int64))
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     dist.broadcast(hdr, src=src, group=group)
     magic, ver, rec_n, total = [int(v) for v in hdr.tolist()]
-    if magic != _MAGIC or ver != 1 or total < _payload_base(rec_n):
+    if magic != _MAGIC or ver != 1 or rec_n < 0 or total <= 0 or _payload_base(rec_n) > total:
         raise RuntimeError("broadcast_quant_state: bad header %r" % ((magic, ver, rec_n, total),))
     if rank != src:
         arena = torch.empty(total, dtype=torch.uint8, device=dev)
@@ -220,13 +274,24 @@ def broadcast_quant_state(qnn: QuantModel, rank: int, src: int = 0, group=None, 
     return stats
 
 
-def release_fp_weights(qnn: QuantModel) -> int:
+def release_fp_weights(qnn: QuantModel, mp_weight_cfg=None) -> int:
     """Free the fp16 master weight of every Linear whose packed integer form is installed for all its time-ranges
     (ranks > 0 of a sharded job never re-quantize: the master copy would sit beside the arena for nothing - 1.4 GB at
     STDiT-XL/2).  The smoothing vectors (they need max|W| per input channel) are derived and cached first.  Afterwards
-    a re-pack (other bit width, changed statistic) raises instead of quantizing garbage.  Returns the bytes freed."""
+    a re-pack (other bit width, changed statistic) raises instead of quantizing garbage.  With a mixed-precision
+    config the layers that some step range runs in FP or at a width the integer route does not pack (> 8 bits) KEEP
+    their master weight; every other width of the config must have arrived in packed form.  Returns the bytes freed."""
     freed = 0
-    for name, layer, r, t_id in _pack_jobs(qnn):
+    extra, keep = mp_plan_of(qnn, mp_weight_cfg)
+    keep = set(keep) | {n for n, bs in extra.items() if any(b > 8 for b in bs)}
+    jobs = _pack_jobs(qnn, mp_weight_cfg)
+    for name, layer, r, t_id, nb in jobs:
+        if (r, nb) not in layer._packed:
+            raise RuntimeError("%s: no packed weight for time-range %d at %d bits arrived - releasing the master weight "
+                               "would leave this rank unable to run that step range" % (name, r, nb))
+    for name, layer, r, t_id, nb in jobs:
+        if nb != layer.weight_quantizer.n_bits:
+            continue
         saved = layer.cur_timestep_id
         if t_id is not None:
             layer.cur_timestep_id = t_id
@@ -240,8 +305,8 @@ def release_fp_weights(qnn: QuantModel) -> int:
             layer.dequantized_weight_f16(rr, sv)
         layer.cur_timestep_id = saved
     done = set()
-    for name, layer, r, _ in _pack_jobs(qnn):
-        if id(layer) in done or not layer.int_route_ok():
+    for name, layer, r, _, _nb in jobs:
+        if id(layer) in done or not layer.int_route_ok() or name in keep:
             continue
         done.add(id(layer))
         w = layer.weight
@@ -252,14 +317,18 @@ def release_fp_weights(qnn: QuantModel) -> int:
 
 
 def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.REMAIN_FP,
-                            force_collective: bool = False, release_fp: bool = True) -> QuantModel:
+                            force_collective: bool = False, release_fp: bool = True, mp_weight_cfg=None) -> QuantModel:
     """Every rank wraps its (identically seeded / loaded) fp16 model; rank 0 runs weight PTQ and packs;
     the result reaches the other ranks by ONE broadcast.  ``force_collective``: take the arena + broadcast route at
     world 1 too (a one-rank process group: how the RCCL calls are exercised on a single device).  ``release_fp``: ranks
-    other than 0 drop the fp16 master weights of the Linears they received in packed form (:func:`release_fp_weights`)."""
+    other than 0 drop the fp16 master weights of the Linears they received in packed form (:func:`release_fp_weights`).
+    ``mp_weight_cfg``: the timestep-wise mixed-precision weight config the trajectory will switch through
+    (iddpm.TimestepMP) - every bit width it names travels in the arena and the layers it runs in FP keep their master
+    weight, so no rank ever has to re-pack; a job that will switch bit widths WITHOUT naming them here must pass
+    ``release_fp=False``."""
     if world == 1 and not force_collective:
         qnn = synth.quantize_model(model, cfg, fp_layers)
-        prepack(qnn)
+        prepack(qnn, mp_weight_cfg)
         return qnn
     qnn = synth.wrap_model(model, cfg, fp_layers)
     smooth = synth.uses_smooth_quant(cfg)
@@ -271,7 +340,7 @@ def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.R
         else:
             synth.init_weight_quantizers(qnn)
             qnn.set_quant_state(True, True)
-        packed = prepack_into_arena(qnn)      # packed IN the buffer that is broadcast: no second copy on rank 0
+        packed = prepack_into_arena(qnn, mp_weight_cfg)   # packed IN the buffer that is broadcast: no second copy on rank 0
     elif smooth:
         synth.set_inference_state(qnn, cfg, fp_layers)
     else:
@@ -280,7 +349,7 @@ def quantize_and_distribute(model, cfg, rank: int, world: int, fp_layers=synth.R
         qnn.set_quant_state(True, True)
     broadcast_quant_state(qnn, rank, 0, packed=packed)
     if rank != 0 and release_fp:
-        qnn._released_bytes = release_fp_weights(qnn)
+        qnn._released_bytes = release_fp_weights(qnn, mp_weight_cfg)
     return qnn
 
 

@@ -173,7 +173,11 @@ def synthetic_mp_config(qnn: QuantModel, num_steps: int = 20):
     (non-matching) ``fc1_`` / ``fc2_`` FP patterns the released file carries."""
     q = num_steps // 4
     keys = ["%d-%d" % (3 * q - 1, 2 * q), "%d-%d" % (4 * q - 1, 3 * q), "%d-%d" % (q - 1, 0), "%d-%d" % (2 * q - 1, q)]
-    names = sorted("model." + n for n, _ in qnn.quant_layers() if n.startswith("blocks."))
+    if hasattr(qnn, "quant_layers"):
+        names = sorted("model." + n for n, _ in qnn.quant_layers() if n.startswith("blocks."))
+    else:       # the bare model, before wrapping (shard.quantize_and_distribute wants the config up front): same names
+        names = sorted("model." + n for n, m in qnn.named_modules()
+                       if n.startswith("blocks.") and isinstance(m, torch.nn.Linear))
     w = {k: {n: (8 if ".mlp." in n else 4) for n in names} for k in keys}
     w["fp_layers"] = {k: ["fc1_", "fc2_"] for k in keys}
     a = {k: {n: 8 for n in names} for k in keys}

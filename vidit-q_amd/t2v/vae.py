@@ -11,7 +11,7 @@ under /root/reference nor installed here; the reference loads ``sd-vae-ft-ema``)
 the published architecture of that model's decode path (Stable Diffusion VAE: post_quant_conv, conv_in, a mid block
 of ResNet - single-head attention - ResNet, four up blocks of three ResNets with nearest-2x + conv upsampling on the
 first three, GroupNorm(32) - SiLU - conv_out) with diffusers' parameter names, so a ``diffusion_pytorch_model``
-state dict loads with ``strict=False`` minus the encoder keys.  **Parity of the inner decoder is unpinned** (no
+state dict loads ``strict=True`` once its encoder / quant_conv keys are dropped (``load_diffusers_state_dict``).  **Parity of the inner decoder is unpinned** (no
 diffusers, no checkpoint, no network in the build environment); only its shape contract and the wrapper are tested.
 It runs once per prompt, outside the timed loop, as plain PyTorch (MIOpen convolutions): plumbing, not a hot path.
 """
