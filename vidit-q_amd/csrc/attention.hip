@@ -617,9 +617,9 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
         }
         float delta, zp;
         bool small;
-        vq_minmax_to_params(vmin, vmax, 255.0f, delta, zp, small);
+        float inv;
+        vq_row_grid(vmin, vmax, 255.0f, delta, zp, small, inv);
         if (small && tid < 16 && tq < a.T && a.status) atomicOr(a.status, VQ_ST_EPSFILL);
-        const float inv = __fdiv_rn(1.0f, delta);
         const int izx = (int)zp - 128;
         uint32_t csum = 0;
 #pragma unroll
@@ -627,9 +627,11 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
             const int d0 = dt * 16 + 4 * g4;
             if (d0 < D) {
                 uint32_t pk = 0;
+                const float x4[4] = {oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]};
+                float c4[4];
+                rq_round_group<4>(x4, inv, delta, zp, c4);      // one tie test per four codes, packed fp32 math
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rq_round_div(oacc[dt][r], inv, delta) + zp, r, pk);
+                for (int r = 0; r < 4; ++r) pk = __builtin_amdgcn_cvt_pk_u8_f32(c4[r], r, pk);
                 csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
                 *reinterpret_cast<uint32_t*>(codes + tq * CROW + wave * D + d0) = pk ^ 0x80808080u;
             }

@@ -25,17 +25,34 @@ __device__ __forceinline__ float rq_gelu_tanh(float x) {
     const float w = x * fmaf(x * x, -0.044715f * 2.302208198f, -2.302208198f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
 }
+// the same expression on a pair of values as packed fp32 math (v_pk_mul / v_pk_fma / v_pk_add: IEEE-identical to the
+// scalar forms, two elements per issue slot; exp2 and rcp stay per element), result rounded to fp16 like the activation
+// the reference stores between the two Linears
+__device__ __forceinline__ void rq_gelu_tanh8(half8& h) {
+    const float2v c1 = {-0.044715f * 2.302208198f, -0.044715f * 2.302208198f}, c2 = {-2.302208198f, -2.302208198f};
+    const float2v one = {1.0f, 1.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2v x = {(float)h[2 * j], (float)h[2 * j + 1]};
+        const float2v w = x * __builtin_elementwise_fma(x * x, c1, c2);
+        const float2v d = float2v{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + one;
+        const float2v g = x * float2v{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        h[2 * j] = (half_t)g[0];
+        h[2 * j + 1] = (half_t)g[1];
+    }
+}
 
 
 // quantize 8 values -> two packed dwords of (code - cx); returns sum of raw codes
 template <bool SAT8>
-__device__ __forceinline__ uint32_t rq_quant8_t(const float v[8], float inv, float delta, float zp, float qmax,
+__device__ __forceinline__ uint32_t rq_quant8_t(const float (&v)[8], float inv, float delta, float zp, float qmax,
                                                 uint32_t flip, uint2& packed) {
+    float r[8];
+    rq_round_group<8>(v, inv, delta, zp, r);
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float q0 = rq_round_div(v[i], inv, delta) + zp;
-        float q1 = rq_round_div(v[4 + i], inv, delta) + zp;
+        float q0 = r[i], q1 = r[4 + i];
         if constexpr (!SAT8) {
             q0 = __builtin_amdgcn_fmed3f(q0, 0.0f, qmax);
             q1 = __builtin_amdgcn_fmed3f(q1, 0.0f, qmax);
@@ -47,11 +64,37 @@ __device__ __forceinline__ uint32_t rq_quant8_t(const float v[8], float inv, flo
     packed = make_uint2(lo ^ flip, hi ^ flip);
     return sum;
 }
-__device__ __forceinline__ uint32_t rq_quant8(const float v[8], float inv, float delta, float zp, float qmax,
+__device__ __forceinline__ uint32_t rq_quant8(const float (&v)[8], float inv, float delta, float zp, float qmax,
                                               uint32_t flip, uint2& packed) {
     if (qmax == 255.0f) return rq_quant8_t<true>(v, inv, delta, zp, qmax, flip, packed);   // wave-uniform
     return rq_quant8_t<false>(v, inv, delta, zp, qmax, flip, packed);
 }
+
+// quantize 4 values of one lane -> one dword of raw codes (tie test shared by the four, see rq_round_group)
+// SAT8 (8-bit codes): v_cvt_pk_u8_f32 saturates to [0, 255] by itself; other widths clamp first.  The callers pick the
+// instantiation with ONE kernel-uniform branch around their whole store loop (RQ_BY_WIDTH) - as a per-element select it
+// cost a v_med3 + v_cndmask per code.
+template <bool SAT8>
+__device__ __forceinline__ uint32_t rq_quant4(const float (&v)[4], float inv, float delta, float zp, float qmax) {
+    float r[4];
+    rq_round_group<4>(v, inv, delta, zp, r);
+    uint32_t pk = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float q = r[e];
+        if constexpr (!SAT8) q = __builtin_amdgcn_fmed3f(q, 0.0f, qmax);
+        pk = __builtin_amdgcn_cvt_pk_u8_f32(q, e, pk);
+    }
+    return pk;
+}
+#define RQ_BY_WIDTH(qmax_, ...)                                       \
+    if ((qmax_) == 255.0f) {                                          \
+        constexpr bool SAT8_ = true;                                  \
+        __VA_ARGS__                                                   \
+    } else {                                                          \
+        constexpr bool SAT8_ = false;                                 \
+        __VA_ARGS__                                                   \
+    }
 
 // ---------------------------------------------------------------------------
 // plain per-token quantizer, B == 1
@@ -85,11 +128,8 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
         const int c0 = lane * 8 + i * 512;
         if (c0 < C) {
             h[i] = *reinterpret_cast<const half8*>(row + c0);
-            if constexpr (GELU) {   // act(fc1 output) applied here, under the HBM stream, instead of in the GEMM epilogue;
-                                    // rounded to fp16 as the activation the reference stores between the two Linears
-#pragma unroll
-                for (int e = 0; e < 8; ++e) h[i][e] = (half_t)rq_gelu_tanh((float)h[i][e]);
-            }
+            // act(fc1 output) applied here, under the HBM stream, instead of in the GEMM epilogue
+            if constexpr (GELU) rq_gelu_tanh8(h[i]);
         }
     }
     float vmin, vmax;
@@ -157,9 +197,9 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
     }
     float delta, zp;
     bool small;
-    vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+    float inv;
+    vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
     if (small && lane == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
-    const float inv = __fdiv_rn(1.0f, delta);
     const int izx = (int)zp - cx;
 
     int8_t* qrow = xq + (size_t)tok * Kp;
@@ -237,8 +277,10 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i)
             if (lane * 8 + i * 512 < C) {
+                half8 g = hn[i];
+                if constexpr (GELU) rq_gelu_tanh8(g);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) w[i][e] = GELU ? (float)(half_t)rq_gelu_tanh((float)hn[i][e]) : (float)hn[i][e];
+                for (int e = 0; e < 8; ++e) w[i][e] = (float)g[e];
             }
         if (it + 1 < n_it) {                               // next row in flight under this row's arithmetic
             const int tn = tk + stride;
@@ -278,9 +320,9 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_smooth_lds_kernel(
         }
         float delta, zp;
         bool small;
-        vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+        float inv;
+        vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
         if (small && lane == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
-        const float inv = __fdiv_rn(1.0f, delta);
         const int izx = (int)zp - cx;
         int8_t* qrow = xq + tok * Kp;
         uint32_t csum = 0;
@@ -390,25 +432,19 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_half_kernel(const half_t
     }
     float delta, zp;
     bool small;
-    vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+    float inv;
+    vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
     if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
-    const float inv = __fdiv_rn(1.0f, delta);
     const int izx = (int)zp - cx;
 
     int8_t* qrow = xq + (size_t)tok * C + hl * 4;
     uint32_t csum = 0;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        uint32_t pk = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float q = rq_round_div((float)h[i][e], inv, delta) + zp;
-            if (qmax != 255.0f) q = __builtin_amdgcn_fmed3f(q, 0.0f, qmax);
-            pk = __builtin_amdgcn_cvt_pk_u8_f32(q, e, pk);
-        }
+    RQ_BY_WIDTH(qmax, _Pragma("unroll") for (int i = 0; i < NIT; ++i) {
+        const float x4[4] = {(float)h[i][0], (float)h[i][1], (float)h[i][2], (float)h[i][3]};
+        const uint32_t pk = rq_quant4<SAT8_>(x4, inv, delta, zp, qmax);
         csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
         if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
-    }
+    })
     int cs = (int)csum;
     VQ_DPP_STEP(int, vq_addi, cs, 0xB1);
     VQ_DPP_STEP(int, vq_addi, cs, 0x4E);
@@ -516,9 +552,9 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_fast_kernel(
     for (int j = 0; j < NOUT; ++j) {
         float delta, zp;
         bool small;
-        vq_minmax_to_params(wave_min_f(vmin[j]), wave_max_f(vmax[j]), qmax, delta, zp, small);
+        float inv;
+        vq_row_grid(wave_min_f(vmin[j]), wave_max_f(vmax[j]), qmax, delta, zp, small, inv);
         if (small && lane == 0 && status) atomicOr(status, VQ_ST_EPSFILL);
-        const float inv = __fdiv_rn(1.0f, delta);
         const int izx = (int)zp - cx;
         int8_t* qrow = o.xq[j] + (size_t)tok * Kp;
         uint32_t csum = 0;
@@ -629,24 +665,17 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
     }
     float delta, zp;
     bool small;
-    vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+    float inv;
+    vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
     if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
-    const float inv = __fdiv_rn(1.0f, delta);
     const int izx = (int)zp - cx;
     int8_t* qrow = xq + (size_t)tok * C + hl * 4;
     uint32_t csum = 0;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        uint32_t pk = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float q = rq_round_div(v[i][e], inv, delta) + zp;
-            if (qmax != 255.0f) q = __builtin_amdgcn_fmed3f(q, 0.0f, qmax);
-            pk = __builtin_amdgcn_cvt_pk_u8_f32(q, e, pk);
-        }
+    RQ_BY_WIDTH(qmax, _Pragma("unroll") for (int i = 0; i < NIT; ++i) {
+        const uint32_t pk = rq_quant4<SAT8_>(v[i], inv, delta, zp, qmax);
         csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
         if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
-    }
+    })
     int cs = (int)csum;
     RQH_REDUCE2(int, vq_addi, cs)
     if (hl == 0 && live) {
@@ -775,24 +804,17 @@ __global__ __launch_bounds__(RQF_THREADS) void smooth_rowquant_half_kernel(
         }
         float delta, zp;
         bool small;
-        vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+        float inv;
+        vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
         if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
-        const float inv = __fdiv_rn(1.0f, delta);
         const int izx = (int)zp - cx;
         int8_t* qrow = xq + (size_t)tok * C + hl * 4;
         uint32_t csum = 0;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            uint32_t pk = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float q = rq_round_div(w[i][e], inv, delta) + zp;
-                if (qmax != 255.0f) q = __builtin_amdgcn_fmed3f(q, 0.0f, qmax);
-                pk = __builtin_amdgcn_cvt_pk_u8_f32(q, e, pk);
-            }
+        RQ_BY_WIDTH(qmax, _Pragma("unroll") for (int i = 0; i < NIT; ++i) {
+            const uint32_t pk = rq_quant4<SAT8_>(w[i], inv, delta, zp, qmax);
             csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
             if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
-        }
+        })
         int cs = (int)csum;
         RQH_REDUCE2(int, vq_addi, cs)
         if (hl == 0 && live) {
@@ -937,24 +959,17 @@ __global__ __launch_bounds__(64 * NWV, 4) void smooth_rowquant_multi_kernel(
             RQH_REDUCE2(float, fmaxf, vmax)
             float delta, zp;
             bool small;
-            vq_minmax_to_params(vmin, vmax, qmax, delta, zp, small);
+            float inv;
+            vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
             if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
-            const float inv = __fdiv_rn(1.0f, delta);
             const int izx = (int)zp - cx;
             int8_t* qrow = o.xq[j] + (size_t)tok * C + hl * 4;
             uint32_t csum = 0;
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                uint32_t pk = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float c = rq_round_div(q[i][e], inv, delta) + zp;
-                    if (qmax != 255.0f) c = __builtin_amdgcn_fmed3f(c, 0.0f, qmax);
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(c, e, pk);
-                }
+            RQ_BY_WIDTH(qmax, _Pragma("unroll") for (int i = 0; i < NIT; ++i) {
+                const uint32_t pk = rq_quant4<SAT8_>(q[i], inv, delta, zp, qmax);
                 csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
                 if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
-            }
+            })
             int cs = (int)csum;
             RQH_REDUCE2(int, vq_addi, cs)
             if (hl == 0 && live) {

@@ -95,6 +95,38 @@ __device__ __forceinline__ float rq_round_div(float x, float inv, float delta) {
     return r;
 }
 
+// The per-token quantizers' inner step for N values of ONE row whose grid (delta, zp) comes from the row's own min / max
+// (so |x / delta| <= qmax <= 255 and x / delta + zp lies in [-0.5, 255.5]): r[i] = rint(x[i] / delta) + zp, bit-identical to
+// the correctly rounded division, as packed fp32 math (gfx950 issues v_pk_fma_f32 / v_pk_add_f32 at the rate of the
+// scalar forms, tools/lab/valu_rate.hip: two elements per issue slot):
+//   t = fma(x, RN(1/delta), zp) is within 3.1e-5 of the exact x / delta + zp (|x / delta| 2^-24 from the reciprocal,
+//   half an ulp of a value < 256 from the one rounding), RN(x / delta) + zp within 1.5e-5 of it: whenever t is not within
+//   1e-4 of a rounding tie, rint(t) == rint(RN(x / delta)) + zp.  The distance to a tie is collected for the whole group
+//   with v_max3_f32 and tested ONCE (a wave-level branch per group instead of one per element: the per-element branches
+//   were ~40 % of the quantizers' issue slots); a group with a value that close to a tie (2e-4 of all values) redoes
+//   those values with the division.  ``inv`` may be the 1-ulp v_rcp_f32 of delta (vq_row_grid): the bound becomes 5.3e-5.
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ void rq_round_group(const float (&x)[N], float inv, float delta, float zp, float (&r)[N]) {
+    static_assert(N % 2 == 0, "pairs");
+    const float2v inv2 = {inv, inv}, zp2 = {zp, zp};
+    float2v t[N / 2];
+    float far = 0.f;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+        t[j] = __builtin_elementwise_fma(float2v{x[2 * j], x[2 * j + 1]}, inv2, zp2);
+        r[2 * j] = __builtin_rintf(t[j][0]);
+        r[2 * j + 1] = __builtin_rintf(t[j][1]);
+        const float2v d = t[j] - float2v{r[2 * j], r[2 * j + 1]};
+        far = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[0]), __builtin_fabsf(d[1])), far);   // v_max3_f32 |a|, |b|, c
+    }
+    if (!(far <= 0.4999f)) {                            // (also taken by a NaN: 0 x inf from a degenerate grid)
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (!(__builtin_fabsf(t[i >> 1][i & 1] - r[i]) <= 0.4999f)) r[i] = rintf(__fdiv_rn(x[i], delta)) + zp;
+    }
+}
+
 __device__ __forceinline__ void vq_minmax_to_params(float xmin, float xmax, float qmax, float& delta, float& zp,
                                                     bool& small) {
     xmin = fminf(xmin, 0.0f);  // x_min[x_min>0] = 0   (base_quantizer.py:192)
@@ -104,4 +136,36 @@ __device__ __forceinline__ void vq_minmax_to_params(float xmin, float xmax, floa
     float d = delta > 0.0f ? delta : VQ_EPS;  // avoid 0/0 in the (flagged) degenerate row
     delta = d;
     zp = rintf(__fdiv_rn(-xmin, d));
+}
+
+// vq_minmax_to_params for the register-resident per-token quantizers, with the row-level divisions trimmed (each is
+// ~12 VALU instructions that all 64 lanes execute; three of them were a tenth of a C = 1152 row's instructions):
+//   delta = RN((max - min) / qmax): for qmax = 255 by Markstein's correction with the constant RN(1/255) (255's
+//     significand is not all ones; exact for every dividend whose residual cannot underflow - checked against the IEEE
+//     quotient on 3 x 10^7 values and every fp16 magnitude), else the division;
+//   inv = v_rcp_f32(delta), 1 ulp: it only feeds the tie-guarded product form of rq_round_group;
+//   zp = rint(-min / delta) through the same guarded product form (exact division when within 1e-4 of a tie).
+// Bit-identical results to vq_minmax_to_params + __fdiv_rn(1, delta) wherever they are used.
+__device__ __forceinline__ void vq_row_grid(float xmin, float xmax, float qmax, float& delta, float& zp, bool& small,
+                                            float& inv) {
+    xmin = fminf(xmin, 0.0f);
+    xmax = fmaxf(xmax, 0.0f);
+    const float a = xmax - xmin;
+    float d;
+    if (qmax == 255.0f && a > 1.0e-30f) {
+        const float r255 = 1.0f / 255.0f;               // RN(1/255), folded at compile time
+        const float q = a * r255;
+        const float e = __builtin_fmaf(-q, 255.0f, a);
+        d = __builtin_fmaf(e, r255, q);
+    } else {
+        d = __fdiv_rn(a, qmax);
+    }
+    small = d < VQ_EPS;
+    d = d > 0.0f ? d : VQ_EPS;
+    delta = d;
+    inv = __builtin_amdgcn_rcpf(d);
+    const float t = -xmin * inv;
+    float r = rintf(t);
+    if (!(fabsf(t - r) <= 0.4999f)) r = rintf(__fdiv_rn(-xmin, d));
+    zp = r;
 }
