@@ -94,40 +94,57 @@ __device__ __forceinline__ void xcd_tile(int bid, int MT, int NTl, int& mt, int&
 // Per-channel dequant parameters of a tile (sw, -zw, cs, bias): loaded into registers BEFORE the first DMA
 // batch is issued and parked in the LDS block behind the epilogue slabs AFTER it (PAR_OFF lies past the end
 // of every ring), so neither the load latency nor the staging sits on the critical path.
-struct ColParams {
+struct ColParams1 {
     float sw, b;
     int nzw, cs;
 };
-template <int BN>
-__device__ __forceinline__ ColParams ring_load_col_params(const GemmArgs& a, int n0, int tid_in = -1,
-                                                          const float* gate_row = nullptr) {
-    ColParams c{0.f, 0.f, 0, 0};
-    const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
-    const int gn = n0 + tx;
-    if (tx < BN && gn < a.N) {
-        c.sw = a.sw[gn];
-        c.nzw = -a.zw[gn];
-        c.cs = a.cs[gn];
-        c.b = a.bias ? a.bias[gn] : 0.f;
-        if (gate_row) {                                // gate * (sx*sw*t + b): folded into the per-channel terms
-            const float g = gate_row[gn];
-            c.sw *= g;
-            c.b *= g;
+// NPT = channels per thread: 1 for the 512-thread workgroups (288 channels), 2 for a 256-thread workgroup
+template <int NPT = 1>
+struct ColParamsT {
+    ColParams1 c[NPT];
+};
+using ColParams = ColParamsT<1>;
+template <int BN, int NT = 512>
+__device__ __forceinline__ ColParamsT<(BN + NT - 1) / NT> ring_load_col_params(const GemmArgs& a, int n0, int tid_in = -1,
+                                                                                const float* gate_row = nullptr) {
+    constexpr int NPT = (BN + NT - 1) / NT;
+    ColParamsT<NPT> r;
+    const int tx0 = tid_in >= 0 ? tid_in : (int)threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        ColParams1 c{0.f, 0.f, 0, 0};
+        const int tx = tx0 + u * NT;
+        const int gn = n0 + tx;
+        if (tx < BN && gn < a.N) {
+            c.sw = a.sw[gn];
+            c.nzw = -a.zw[gn];
+            c.cs = a.cs[gn];
+            c.b = a.bias ? a.bias[gn] : 0.f;
+            if (gate_row) {                            // gate * (sx*sw*t + b): folded into the per-channel terms
+                const float g = gate_row[gn];
+                c.sw *= g;
+                c.b *= g;
+            }
         }
+        r.c[u] = c;
     }
-    return c;
+    return r;
 }
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
-__device__ __forceinline__ void ring_park_col_params(const ColParams& c, uint8_t* smem, int tid_in = -1) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16, int NPT = 1>
+__device__ __forceinline__ void ring_park_col_params(const ColParamsT<NPT>& c, uint8_t* smem, int tid_in = -1) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
-    static_assert(BN <= NT, "one channel per thread");
+    static_assert(BN <= NPT * NT, "NPT channels per thread");
     constexpr int PAR_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD);
-    const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
-    if (tx < BN) {
-        reinterpret_cast<float*>(smem + PAR_OFF)[tx] = c.sw;
-        reinterpret_cast<int*>(smem + PAR_OFF)[BN + tx] = c.nzw;
-        reinterpret_cast<int*>(smem + PAR_OFF)[2 * BN + tx] = c.cs;
-        reinterpret_cast<float*>(smem + PAR_OFF)[3 * BN + tx] = c.b;
+    const int tx0 = tid_in >= 0 ? tid_in : (int)threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        const int tx = tx0 + u * NT;
+        if (tx < BN) {
+            reinterpret_cast<float*>(smem + PAR_OFF)[tx] = c.c[u].sw;
+            reinterpret_cast<int*>(smem + PAR_OFF)[BN + tx] = c.c[u].nzw;
+            reinterpret_cast<int*>(smem + PAR_OFF)[2 * BN + tx] = c.c[u].cs;
+            reinterpret_cast<float*>(smem + PAR_OFF)[3 * BN + tx] = c.c[u].b;
+        }
     }
 }
 
@@ -181,7 +198,7 @@ __device__ __forceinline__ const float* ring_tile_gate_row(const GemmArgs& a, in
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
 __device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* smem, int m0, int n0, int tid_in = -1,
                                                   const float* gate_row = nullptr) {
-    const ColParams colp = ring_load_col_params<BN>(a, n0, tid_in, gate_row);
+    const auto colp = ring_load_col_params<BN, 64 * WAVES_M * WAVES_N>(a, n0, tid_in, gate_row);
     const RowParams rowp = ring_load_row_params<BM>(a, m0, tid_in);
     ring_park_col_params<BM, BN, WAVES_M, WAVES_N, PAD>(colp, smem, tid_in);
     ring_park_row_params<BM, BN, WAVES_M, WAVES_N, PAD>(rowp, smem, tid_in);

@@ -29,7 +29,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     constexpr int PLAST = PIECES - (PPW - 1) * NW;
     constexpr int BARJ = TN - 2;                      // after the last fragment read of the current stage
     constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (next tile)
-    static_assert((TM == 4 || TM == 2) && TN >= 3 && TN % 3 == 0, "fragment rings below");
+    static_assert((TM == 8 || TM == 4 || TM == 2) && TN >= 3 && TN % 3 == 0, "fragment rings below");
     static_assert(BN * WROW % 1024 == 0 && STAGE % 128 == 0, "whole pieces, 128-byte aligned stages");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
 
@@ -240,7 +240,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     // last MFMAs (wrong columns in rows of the slower waves; found by test_gemm_low_bit_weights).  There the global
     // loads are issued first and the LDS writes wait for a workgroup barrier.
     constexpr bool PAR_IN_RING = NW * WTM * (WTN * 2 + 16) < 2 * STAGE;
-    const ColParams colp = ring_load_col_params<BN>(a, n0, tid, gate_row);
+    const auto colp = ring_load_col_params<BN, 64 * NW>(a, n0, tid, gate_row);
     const RowParams rowp = ring_load_row_params<BM>(a, m0, tid);
     if constexpr (PAR_IN_RING) __syncthreads();
     ring_park_col_params<BM, BN, WAVES_M, WAVES_N>(colp, smem, tid);
