@@ -91,8 +91,11 @@ int vq_rowquant(const void* x, const void* add_rows, int n_add, int add_div, con
  * applied to the fc1 output) followed by the fc2 activation quantizer (qdiff/models/quant_layer.py:136-160 +
  * qdiff/quantizer/dynamic_quantizer.py:16-45).  The fc1 GEMM is then launched with VQ_EPI_NONE: the activation's
  * exp/rcp run under this HBM-bound kernel instead of the MFMA-bound GEMM epilogue.  GELU output is rounded to fp16
- * before quantization (the activation dtype of the reference pipeline).  B must be 1 (VQ_EUNSUP otherwise: token
- * scales shared over a batch need the two-pass generic kernel).  Outputs as vq_rowquant. */
+ * before quantization (the activation dtype of the reference pipeline).  B = 1, or B = 2 with x [2, n_tok, C] and the
+ * grid of a token shared by its two samples (base_quantizer.py:185: the t2i loop's uncond | cond forward; outputs
+ * indexed by row = sample * n_tok + token with the shared step replicated, as vq_rowquant writes them; with a smoothing
+ * vector only rows longer than 1536 channels).  Larger batches: VQ_EUNSUP (use the GEMM's GELU epilogue + vq_rowquant).
+ * Outputs as vq_rowquant. */
 int vq_gelu_rowquant(const void* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx, int32_t* R,
                      int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream);
 

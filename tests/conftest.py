@@ -12,6 +12,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# what this pytest session selected and how it went: written into the parity record, so that a figure can never be read
+# without knowing which tests produced the file (round 3's record had been rebuilt by a run that deselected the
+# full-depth tests)
+_RUN = {"args": [], "selected": 0, "deselected": 0, "passed": [], "failed": [], "skipped": []}
+
+
+def pytest_collection_modifyitems(config, items):
+    _RUN["args"] = [str(a) for a in config.invocation_params.args]
+    _RUN["selected"] = len(items)
+
+
+def pytest_deselected(items):
+    _RUN["deselected"] += len(items)
+
+
+def pytest_runtest_logreport(report):
+    if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+        _RUN[report.outcome if report.outcome in ("passed", "failed", "skipped") else "failed"].append(report.nodeid)
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch
@@ -48,14 +68,10 @@ def parity():
     if rec:
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, "parity.json")
-        old = {}
-        if os.path.exists(path):
-            try:
-                with open(path) as f:
-                    old = json.load(f)
-            except Exception:
-                old = {}
-        old.update(rec)
-        with open(path, "w") as f:
-            json.dump(old, f, indent=1, sort_keys=True)
+        # a FRESH file per session (no merging with an older record: stale keys would survive a renamed test), with
+        # the session's own selection beside the figures
+        rec["_run"] = {"pytest_args": _RUN["args"], "selected": _RUN["selected"], "deselected": _RUN["deselected"],
+                       "passed": len(_RUN["passed"]), "failed": sorted(_RUN["failed"]), "skipped": sorted(_RUN["skipped"]),
+                       "tests_that_recorded_or_passed": sorted(_RUN["passed"])}
+        with open(os.path.join(out, "parity.json"), "w") as f:
+            json.dump(rec, f, indent=1, sort_keys=True)

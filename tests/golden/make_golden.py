@@ -861,6 +861,51 @@ def xl_width(R):
     npz("xl_width_ref.npz", **out)
 
 
+def xl_depth6(R):
+    """Error growth with depth at FULL WIDTH, on the reference itself (round-3 review, parity item 4b): a depth-6 STDiT at
+    C = 1152 / 16 heads / mlp 4608 over 64 tokens (T = 4, S = 16), W8A8 dynamic, cfg_split, weights from a seed
+    (tests/helpers.py::seeded_state_dict; NOT stored) - every block output and the model output in the reference's fp32
+    mode and in its fp16 mode.  The GPU test holds the HIP path, block by block, to 1.25 x the reference's OWN fp16-mode
+    drift at the same depth and width: the sqrt(depth) law the full-depth tests rely on, anchored on the reference at
+    full width instead of at hidden 64."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict
+    seed = XL_SEED + 100
+    out = {"seed": np.array(seed)}
+    cfg = dict(input_size=(4, 8, 8), depth=6, hidden_size=1152, num_heads=16, model_max_length=12, caption_channels=64)
+    m = R.STDiT(enable_flashattn=False, **cfg)
+    m.load_state_dict(seeded_state_dict(m, seed), strict=True)
+    m.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    x = h(torch.randn(1, 4, 4, 8, 8, generator=g))
+    y = h(torch.randn(2, 1, 12, 64, generator=g) * 0.5)
+    mask = torch.zeros(1, 12, dtype=torch.int64)
+    mask[0, :10] = 1
+    t = torch.tensor([733])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    with torch.no_grad():
+        wq = ref_import.wq_cfg(8, mixed_precision=[4, 6, 8])
+        aq = ref_import.aq_cfg(T=4, S=16, n_prompt=12)
+        qnn = R.QuantModel(m, wq, aq)
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.fp_layer_list = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+        qnn.set_quant_state(True, False)
+        qnn(x, t, y[:1], mask=mask)
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_init_done("activation")
+        qnn.set_quant_state(True, True)
+        qnn.cfg_split = True
+        for tag, q, yy in (("", qnn, y[:1]), ("_ref_fp16", _half_copy(qnn), y[:1].half())):
+            blocks = []
+            hooks = [b.register_forward_hook(lambda mod, i, o: blocks.append(o.clone())) for b in q.model.blocks]
+            out["w8a8_out" + tag] = q(x, t, yy, mask=mask).float()
+            for hk in hooks:
+                hk.remove()
+            for i, b in enumerate(blocks):
+                out["w8a8_block%d%s" % (i, tag)] = b.float()
+    npz("xl_depth6_ref.npz", **out)
+
+
 def tiny_vae_wrapper():
     """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
     a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
@@ -950,6 +995,8 @@ def main():
             six_bit_models(R)
         if want("xl_width"):
             xl_width(R)
+        if want("xl_depth6"):
+            xl_depth6(R)
         if want("vae"):
             tiny_vae_wrapper()
         if want("attn_kats"):

@@ -736,6 +736,31 @@ def test_gelu_rowquant_matches_gelu_then_rowquant(ops, dev, C, smooth):
     assert rel_l2(deq.cpu(), ref.cpu()) < 1e-2      # 8-bit quantization noise itself
 
 
+@pytest.mark.parametrize("C,n_tok,smooth", [(4608, 515, False), (4608, 300, True), (1152, 131, False), (320, 65, False)])
+def test_gelu_rowquant_pair_shares_the_grid_over_the_batch(ops, dev, C, n_tok, smooth):
+    """vq_gelu_rowquant for the uncond | cond pair (B = 2): GELU, then ONE grid per token from the min / max over its two
+    samples (base_quantizer.py:185) - against vq_rowquant's pair kernel applied to the separately computed fp16 activation
+    (<= 1 code step where the kernel's rcp / exp2 GELU and torch's differ in the last fp16 ulp), and the steps / zero points
+    against the oracle's batch-shared quantizer of that activation."""
+    from oracle import fakequant as fq
+    h = h16(2, n_tok, C, scale=2.0, seed=C + n_tok).to(dev)
+    s = (torch.rand(C, generator=torch.Generator().manual_seed(2)) + 0.5).float().to(dev) if smooth else None
+    qa = ops.gelu_rowquant(h, s=s)
+    act = torch.nn.functional.gelu(h.float(), approximate="tanh").half()
+    qb = ops.rowquant(act, s=s)
+    assert qa.xq.shape == qb.xq.shape == (2 * n_tok, ops.pad128(C))
+    assert (qa.xq == qb.xq).float().mean().item() > 0.99
+    assert (qa.xq.int() - qb.xq.int()).abs().max().item() <= 1
+    assert torch.allclose(qa.sx, qb.sx, rtol=2e-3)
+    assert torch.equal(qa.sx[:n_tok], qa.sx[n_tok:]) and torch.equal(qa.zx[:n_tok], qa.zx[n_tok:])   # shared over the pair
+    a32 = act.float().cpu()
+    if smooth:
+        a32 = a32 / s.cpu()
+    d, z, _ = fq.minmax_params(a32.permute(1, 0, 2).reshape(n_tok, -1), 8)       # one grid per token over both samples
+    assert torch.allclose(qa.sx[:n_tok].cpu(), d.reshape(-1), rtol=2e-3)
+    assert (qa.zx[:n_tok].cpu() + 128 - z.reshape(-1).int()).abs().max().item() <= 1
+
+
 def test_gemm_i8_batched_equals_separate_launches(ops, dev):
     """vq_gemm_i8_batched: one activation, stacked weight sets (the kv_linear of every block on the same prompt
     tokens) - bit-identical to one vq_gemm_i8 launch per weight set."""
@@ -760,9 +785,12 @@ def test_gemm_i8_batched_equals_separate_launches(ops, dev):
 @pytest.mark.parametrize("N,K", [(1152, 1152), (4608, 1152), (1152, 4608)])
 def test_gemm_full_size_against_the_library_integer_matmul(ops, dev, N, K, w_bits):
     """BASELINE size (16384 tokens): the int32 contraction of the codes recomputed by the vendor library
-    (torch._int_mm), the rank-one zero-point terms and the dequantisation in plain torch - an independent route to the
-    same numbers.  The fused kernel rounds once (fma) where torch rounds twice, so: at most one fp16 ulp apart, on at
-    most 0.1 % of the outputs."""
+    (torch._int_mm), the rank-one zero-point terms exact in int64 and the dequantisation in fp64 - an independent route
+    to the same numbers.  The kernel's epilogue (round 4: packed fp32, gemm_common.h ring_dequant<true>) evaluates
+    y = (sx sw) acc + (sx R)(sw (-zw)) + (sx (-zx))(sw cs) + b with one fp32 rounding per product / sum, so it may sit a
+    few fp32 ulps OF THE LARGEST TERM away from the exactly rounded value before the fp16 rounding: per output at most
+    one fp16 ulp plus that, on a few per cent of the outputs, and the rel-L2 distance from the un-rounded result stays
+    the fp16 rounding's own 2.9e-4."""
     M = 16384
     x = h16(1, M, K, scale=1.5, seed=K).to(dev)
     W = h16(N, K, scale=0.04, seed=N + K).to(dev)
@@ -777,13 +805,19 @@ def test_gemm_full_size_against_the_library_integer_matmul(ops, dev, N, K, w_bit
         g = pw.wq.view(N, pw.Kp // 8, 4).to(torch.int16)    # code[k0 + j] (low) and code[k0 + 4 + j] (high)
         ws = torch.cat([g & 15, g >> 4], dim=2).reshape(N, pw.Kp).to(torch.int8)
     acc = torch._int_mm(qa.xq, ws.t().contiguous()).long()
-    tt = acc - pw.zw.long()[None, :] * qa.R.long()[:, None] - qa.zx.long()[:, None] * pw.cs.long()[None, :]
+    t_w = pw.zw.long()[None, :] * qa.R.long()[:, None]
+    t_x = qa.zx.long()[:, None] * pw.cs.long()[None, :]
+    tt = acc - t_w - t_x
     assert int(tt.abs().max()) < 2 ** 31
-    ref = ((qa.sx[:, None] * pw.sw[None, :]) * tt.float() + b[None, :]).half().float()
+    S = qa.sx.double()[:, None] * pw.sw.double()[None, :]
+    exact = S * tt.double() + b.double()[None, :]
+    ref = exact.half().float()
     diff = (out - ref).abs()
     ulp = 2.0 ** -10 * ref.abs().clamp(min=2.0 ** -14)
-    assert bool((diff <= ulp).all())
-    assert float((diff > 0).float().mean()) < 1e-3
+    slack = (4 * 2.0 ** -24 * (S * (acc.abs() + t_w.abs() + t_x.abs()).double() + b.abs().double()[None, :])).float()
+    assert bool((diff <= ulp + slack).all())
+    assert float((diff > 0).float().mean()) < 5e-2
+    assert float((out.double() - exact).norm() / exact.norm()) < 3.2e-4
 
 
 @pytest.mark.parametrize("w_bits", [8, 4])

@@ -17,7 +17,8 @@ VGPR_FORM = {"attention.hip", "gemm_i8.hip"}
 def _flags(src: str):
     env = os.environ.get("VQ_VGPR_FORM")
     vg = set(env.split(",")) if env is not None else VGPR_FORM
-    return FLAGS + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if src in vg else [])
+    extra = os.environ.get("VQ_EXTRA_HIPCC_FLAGS", "").split()       # A/B builds (e.g. -DVQ_GEMM_FP_DEQUANT=0 into out_dir)
+    return FLAGS + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if src in vg else []) + extra
 
 
 def _hipcc() -> str:

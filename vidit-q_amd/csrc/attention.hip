@@ -1286,6 +1286,297 @@ static int launch_attn32d(const AttnArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
+// attn_cross32_kernel (round 4): cross attention against a SHORT key/value sequence (<= 128 keys) as attn_fwd32d_kernel
+// with the loops interchanged - K and V of ONE (sequence, head) pair are brought into LDS ONCE per workgroup (two 64-key
+// tile images, the layouts and fragment reads of attn_fwd32d_kernel: K rows KROW bytes read as ds_read_b128, V row-major
+// read with ds_read_b64_tr_b16, ones column for the row sums), then the workgroup walks its slice of the query tiles:
+// 32 queries per wave, no DMA, no barrier and no LDS write inside the walk, the next tile's Q fragments requested
+// before the current tile's MFMAs.  Counters of the register-resident kernel it replaces (attn_cross_reg_kernel:
+// 33.7 us for 80 MB, profiles/r04_hbm_kernels_pmc.md): 160 of its 256 VGPRs hold K / V^T, which leaves two waves per
+// SIMD with ONE 16-query sub-tile in flight each (SQ_WAIT_ANY 0.49, 1.3 resident waves per SIMD on average), and every
+// one of its 2048 waves re-reads and transposes its head's K / V in a ~40-instruction-per-key-row prologue (75 MB of L2
+// reads - as much as the kernel's HBM traffic).  Here a wave needs ~128 VGPRs: four waves per SIMD, 32 queries each,
+// and the K / V images are staged by LDS-DMA once per 8 waves.
+// ---------------------------------------------------------------------------
+template <int D, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs a, int nslice) {
+    using C = Att8Cfg<D, NW>;
+    constexpr int KT = 64, KTB = C::KTILE, VRB = 192, VT = KT * VRB;
+    constexpr int KSL = C::KROW / 16, VSL = VRB / 16;       // 16-byte slots per row
+    constexpr int NKI = KSL, NVI = VSL, NI = NKI + NVI, IPW = (NI + NW - 1) / NW;   // wave-instructions per 64-key tile
+    static_assert(D * 2 + 2 <= VRB && C::DT * 64 <= VRB, "dims + ones column inside a row; every 32-dim tile readable");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    // workgroup -> (query slice, head, sequence): all heads of one slice on ONE XCD (bid % 8), next to each other in its
+    // dispatch order - their 144-byte q / o row segments share cache lines, which then meet in that XCD's L2
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int G = a.n_seq * a.H;
+    const int slice = (idx / G) * 8 + xcd, pair = idx % G;
+    if (slice >= nslice) return;
+    const int seq = pair / a.H, h = pair - seq * a.H;
+    int kv_len = a.Lk;
+    const half_t* kbase;
+    const half_t* vbase;
+    if (a.kv_off) {
+        const int o0 = a.kv_off[seq];
+        kv_len = a.kv_off[seq + 1] - o0;
+        kbase = a.k + (long)o0 * a.kv_tok_stride + h * D;
+        vbase = a.v + (long)o0 * a.kv_tok_stride + h * D;
+    } else {
+        kbase = a.k + (long)seq * a.kv_seq_stride + h * D;
+        vbase = a.v + (long)seq * a.kv_seq_stride + h * D;
+    }
+    kv_len = kv_len < 2 * KT ? kv_len : 2 * KT;            // host guarantees <= 128
+    const int nkt = (kv_len + KT - 1) / KT;
+    const int strideB = (int)a.kv_tok_stride * 2;
+    const unsigned nrec = kv_len > 0 ? (unsigned)(kv_len - 1) * (unsigned)strideB + D * 2 : 0u;
+    // ---- prologue: both tile images by LDS-DMA (rows past the last key are outside num_records: zeros)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const unsigned t0 = (unsigned)kt * (unsigned)KT * (unsigned)strideB;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int j = wave + NW * i;                   // wave-uniform instruction index: K tile first, then V
+            if (j < NI) {
+                const bool isk = j < NKI;
+                const int slot = (isk ? j : j - NKI) * 64 + lane;
+                const int row = isk ? slot / KSL : slot / VSL;
+                const int piece = slot - row * (isk ? KSL : VSL);
+                const int voff = row * strideB + piece * 16;
+                const uint8_t* b = reinterpret_cast<const uint8_t*>(isk ? kbase : vbase) + t0;
+                const unsigned long ba = (unsigned long)b;
+                const int4v rs = {(int)__builtin_amdgcn_readfirstlane((unsigned)ba),
+                                  (int)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                                  (int)__builtin_amdgcn_readfirstlane(nrec > t0 ? nrec - t0 : 0u), 0x00020000};
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem +
+                    (isk ? kt * KTB + j * 1024 : 2 * KTB + kt * VT + (j - NKI) * 1024));
+                if (piece < C::CHD)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff), "s"(rs)
+                                 : "memory", "m0");
+            }
+        }
+    }
+    for (int i = tid; i < 2 * KT * 3; i += 64 * NW) {   // pad columns of both V images: column D = 1.0, the rest 0
+        const int r = i / 3, ch = i % 3;
+        *reinterpret_cast<int4v*>(smem + 2 * KTB + r * VRB + D * 2 + ch * 16) = int4v{ch == 0 ? 0x00003c00 : 0, 0, 0, 0};
+    }
+    const int nqt = (a.Lq + 32 * NW - 1) / (32 * NW);
+    const half_t* qseq = a.q + (long)seq * a.q_seq_stride + h * D;
+    half_t* oseq = a.o + (long)seq * a.o_seq_stride + h * D;
+    // Q tiles: each wave's 32 rows x D go global -> LDS by LDS-DMA into a PRIVATE image (rows of KROW bytes like the K
+    // image: a wave-instruction covers 64 consecutive 16-byte slots = ~7 whole 144-byte row segments - the per-lane
+    // fragment loads this replaces touched 32 rows x 32 bytes per instruction), requested one tile ahead; the MFMA
+    // operand fragments are then ds_read_b128 of that image (conflict-free: odd number of slots per row).
+    constexpr int QSL = C::KROW / 16, QW = 32 * C::KROW, NQI = (32 * QSL + 63) / 64;
+    uint8_t* qreg = smem + 2 * KTB + 2 * VT + wave * QW;
+    const unsigned qdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)qreg);
+    int qvoff[NQI];
+    bool qok[NQI];
+#pragma unroll
+    for (int i = 0; i < NQI; ++i) {
+        const int slot = i * 64 + lane, row = slot / QSL, piece = slot - row * QSL;
+        qok[i] = row < 32 && piece < C::CHD;
+        qvoff[i] = row * (int)a.q_tok_stride * 2 + piece * 16;
+    }
+    auto issue_q = [&](int qt) __attribute__((always_inline)) {
+        int q0 = qt * (32 * NW) + wave * 32;
+        const int last = a.Lq - 1;
+        const int nrows = q0 > last ? 0 : (last - q0 + 1 < 32 ? last - q0 + 1 : 32);
+        q0 = q0 > last ? last : q0;
+        const unsigned long ba = (unsigned long)(qseq + (long)q0 * a.q_tok_stride);
+        // rows past the last query are outside num_records: they land as zeros
+        const unsigned nr = nrows > 0 ? (unsigned)(nrows - 1) * (unsigned)a.q_tok_stride * 2u + D * 2 : 0u;
+        const int4v rs = {(int)__builtin_amdgcn_readfirstlane((unsigned)ba),
+                          (int)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                          (int)__builtin_amdgcn_readfirstlane(nr), 0x00020000};
+#pragma unroll
+        for (int i = 0; i < NQI; ++i) {
+            const unsigned dst = qdst + i * 1024;
+            if (qok[i])
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(qvoff[i]), "s"(rs)
+                             : "memory", "m0");
+        }
+    };
+    int qt = slice;
+    if (qt < nqt) issue_q(qt);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the K / V images (and the first Q tile) have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const uint8_t* q_l = qreg + l31 * C::KROW;
+    int stores_behind = 0;                                 // store instructions issued after the Q DMA in flight (wave-uniform)
+    constexpr int NST = (D / 8 + 1) / 2;                   // store instructions per tile (see the epilogue)
+    const int vtr0 = (4 * g + ((lane & 15) >> 2)) * VRB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    constexpr int LD_T = D / 32, LD_R = D % 32;
+    constexpr int LD_G = (LD_R >> 2) & 1, LD_REG = (LD_R & 3) + 4 * (LD_R >> 3);
+    const int nhalf = (kv_len + 31) / 32;                  // 32-key half tiles that hold keys (wave-uniform, 1..4)
+    const uint8_t* k_l = smem + l31 * C::KROW;
+    const uint8_t* v_l = smem + 2 * KTB + vtr0;
+
+    for (; qt < nqt; qt += nslice) {
+        const int qnext = qt + nslice;
+        // this tile's Q image has landed once at most the stores issued behind its DMA are outstanding (in-order vmcnt)
+        if (stores_behind == NST) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        half8 qf[C::KS];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int d0 = ks * 16 + 8 * g;
+            qf[ks] = *reinterpret_cast<const half8*>(q_l + (d0 < D ? d0 : 0) * 2);
+            if (d0 >= D)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // fragments are in registers: the image is free
+        if (qnext < nqt) issue_q(qnext);                              // next tile: in flight under this tile's work
+        float16v oacc[C::DT];
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+        float m_run = -INFINITY;
+#pragma nounroll
+        for (int hf = 0; hf < nhalf; ++hf) {               // the image rows of half hf: K rows hf * 32.., V rows the same
+            float16v s;
+            const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            {
+                half8 kf[C::KS];
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks) {
+                    const int d0 = ks * 16 + 8 * g;
+                    kf[ks] = *reinterpret_cast<const half8*>(k_l + hf * 32 * C::KROW + (d0 < D ? d0 : 0) * 2);
+                }
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ++ks)
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+            }
+            union VF {
+                half8 v;
+                h4_t h[2];
+            };
+            VF vf[2 * C::DT];                              // V^T fragments: requested here, they fly under the softmax
+#pragma unroll
+            for (int idx2 = 0; idx2 < 2 * C::DT; ++idx2) {
+                const int kk = 2 * hf + idx2 / C::DT, dt = idx2 % C::DT;   // 16-key step kk of the (contiguous) V images
+                const uint8_t* vp = v_l + (16 * kk) * VRB + dt * 64;
+                vf[idx2].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp));
+                vf[idx2].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp + 8 * VRB));
+            }
+            if ((hf + 1) * 32 > kv_len) {                  // wave-uniform: the ragged last half
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (hf * 32 + (r & 3) + 8 * (r >> 2) + 4 * g >= kv_len) s[r] = -INFINITY;
+            }
+            float mloc;
+            {
+                float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+                mx = fmaxf(mx, s[15]);
+                const unsigned mb = __builtin_bit_cast(unsigned, mx);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            }
+            if (__any((mloc - m_run) * a.c > 8.0f)) {
+                const float m_new = fmaxf(m_run, mloc);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * a.c);
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                m_run = m_new;
+            }
+            const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * a.c;
+            half8 pf[2];
+            {
+                const float2v cc2 = {a.c, a.c}, mm2 = {-mc, -mc};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    float2v t = {s[r], s[r + 1]};
+                    t = __builtin_elementwise_fma(t, cc2, mm2);      // v_pk_fma_f32
+                    pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(t[0]);
+                    pf[r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t[1]);
+                }
+            }
+#pragma unroll
+            for (int idx2 = 0; idx2 < 2 * C::DT; ++idx2) {
+                const int dt = idx2 % C::DT;
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx2].v, pf[idx2 / C::DT], oacc[dt], 0, 0, 0);
+            }
+        }
+        float l_run = oacc[LD_T][LD_REG];
+        l_run = __shfl(l_run, l31 + 32 * LD_G);
+        const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
+        // O^T leaves the matrix core with 4 consecutive dims per lane and (dt, rg) group, the partner lane (g ^ 1) holding
+        // the other half of each 8-dim group: one v_permlane32_swap per dword turns two groups into 8 consecutive dims
+        // per lane - 16-byte stores, 32 contiguous bytes per row and instruction instead of 16
+        const int qi = qt * (32 * NW) + wave * 32 + l31;
+        const bool wave_live = qt * (32 * NW) + wave * 32 < a.Lq;      // wave-uniform
+        if (wave_live) {
+            half_t* orow = oseq + (long)(qi < a.Lq ? qi : a.Lq - 1) * a.o_tok_stride;
+            constexpr int NG = D / 8;                       // 8-dim groups
+#pragma unroll
+            for (int p2 = 0; p2 < NG / 2; ++p2) {
+                const int ga = 2 * p2, gb = 2 * p2 + 1;     // groups: dt = grp / 4, rg = grp % 4
+                uint32_t A[2], B[2];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    const h2_t ha = {(half_t)(oacc[ga / 4][(ga % 4) * 4 + 2 * w] * inv), (half_t)(oacc[ga / 4][(ga % 4) * 4 + 2 * w + 1] * inv)};
+                    const h2_t hb = {(half_t)(oacc[gb / 4][(gb % 4) * 4 + 2 * w] * inv), (half_t)(oacc[gb / 4][(gb % 4) * 4 + 2 * w + 1] * inv)};
+                    A[w] = __builtin_bit_cast(uint32_t, ha);
+                    B[w] = __builtin_bit_cast(uint32_t, hb);
+                }
+                // swap(A, B): first result = {low lanes: A of g = 0, high lanes: B of g = 0}, second = {A of g = 1, B of g = 1}
+                const auto s0 = __builtin_amdgcn_permlane32_swap(A[0], B[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(A[1], B[1], false, false);
+                const int4v ov = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+                if (qi < a.Lq) *reinterpret_cast<int4v*>(orow + 16 * p2 + 8 * g) = ov;
+            }
+            if constexpr (NG % 2 == 1) {                    // the odd last group: 8-byte stores as before
+                constexpr int gl = NG - 1;
+                half4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[gl / 4][(gl % 4) * 4 + e] * inv);
+                if (qi < a.Lq) *reinterpret_cast<half4*>(orow + 8 * gl + 4 * g) = ov;
+            }
+            stores_behind = NST;
+        } else {
+            stores_behind = 0;
+        }
+    }
+}
+
+template <int D>
+static int launch_cross32(const AttnArgs& a, hipStream_t st) {
+    constexpr int NW = 8;
+    constexpr int LDS = 2 * Att8Cfg<D, 8>::KTILE + 2 * 64 * 192 + NW * 32 * Att8Cfg<D, 8>::KROW;
+    auto k = attn_cross32_kernel<D, NW>;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    static int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    // two 8-wave workgroups per CU (four waves per SIMD); the (sequence, head) pairs share the chip, every workgroup
+    // walks >= 1 query tile of 256
+    const int G = a.n_seq * a.H, nqt = (a.Lq + 32 * NW - 1) / (32 * NW);
+    int nslice = (2 * ncu + G - 1) / G;
+    nslice = nslice < 1 ? 1 : (nslice > nqt ? nqt : nslice);
+    const int s8 = (nslice + 7) / 8;                      // slices are dealt to the 8 XCDs: grid padded to a multiple
+    hipLaunchKernelGGL(k, dim3(8 * s8 * G), dim3(64 * NW), LDS, st, a, nslice);
+    return vq_check_launch();
+}
+
+// ---------------------------------------------------------------------------
 // attn_cross_reg_kernel: cross attention against a SHORT key/value sequence (<= 128 keys: the <= 120 prompt tokens of
 // STDiT), head_dim 72.  attn_fwd_kernel moved the algorithmic 78 MB in 42 us (1.9 TB/s): 2048 workgroups each staged
 // the same K/V tile pair through LDS, read their queries, and ran two short flash iterations behind barriers.  Here
@@ -1521,6 +1812,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     static const bool old_kernel = getenv("VQ_ATTN_V1") != nullptr;
     // short key/value sequences with a known bound (cross attention over <= 128 prompt tokens): K, V^T in registers
     static const bool no_reg = getenv("VQ_ATTN_CROSS_REG") && atoi(getenv("VQ_ATTN_CROSS_REG")) == 0;   // measurement switch
+    // VQ_ATTN_CROSS=reg keeps the round-1 register-resident kernel (A/B measurements); default: K / V resident in LDS
+    static const bool cross_reg = getenv("VQ_ATTN_CROSS") && getenv("VQ_ATTN_CROSS")[0] == 'r';
+    if (!old_kernel && !no_reg && !cross_reg && a.Lk > 0 && a.Lk <= 128 && a.Lq >= 256 &&
+        (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31))
+        return launch_cross32<D>(a, st);
     if (D == 72 && !old_kernel && !no_reg && a.Lk > 0 && a.Lk <= 128 && a.H % 8 == 0 && a.Lq >= 64) return launch_cross_reg(a, st);
     if (!old_kernel && !a.kv_off && a.Lk > 128 && a.Lq >= 96)
     {

@@ -130,7 +130,9 @@ __device__ __forceinline__ ColParamsT<(BN + NT - 1) / NT> ring_load_col_params(c
     }
     return r;
 }
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16, int NPT = 1>
+// FP (round 4): the zero-point terms are parked as fp32 PRODUCTS with the scale - P = sw * (-zw), Q = sw * cs per
+// channel, U = sx * R, V = sx * (-zx) per token - for the float form of the dequantisation (ring_dequant below).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16, bool FP = false, int NPT = 1>
 __device__ __forceinline__ void ring_park_col_params(const ColParamsT<NPT>& c, uint8_t* smem, int tid_in = -1) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     static_assert(BN <= NPT * NT, "NPT channels per thread");
@@ -141,8 +143,13 @@ __device__ __forceinline__ void ring_park_col_params(const ColParamsT<NPT>& c, u
         const int tx = tx0 + u * NT;
         if (tx < BN) {
             reinterpret_cast<float*>(smem + PAR_OFF)[tx] = c.c[u].sw;
-            reinterpret_cast<int*>(smem + PAR_OFF)[BN + tx] = c.c[u].nzw;
-            reinterpret_cast<int*>(smem + PAR_OFF)[2 * BN + tx] = c.c[u].cs;
+            if constexpr (FP) {
+                reinterpret_cast<float*>(smem + PAR_OFF)[BN + tx] = c.c[u].sw * (float)c.c[u].nzw;
+                reinterpret_cast<float*>(smem + PAR_OFF)[2 * BN + tx] = c.c[u].sw * (float)c.c[u].cs;
+            } else {
+                reinterpret_cast<int*>(smem + PAR_OFF)[BN + tx] = c.c[u].nzw;
+                reinterpret_cast<int*>(smem + PAR_OFF)[2 * BN + tx] = c.c[u].cs;
+            }
             reinterpret_cast<float*>(smem + PAR_OFF)[3 * BN + tx] = c.c[u].b;
         }
     }
@@ -167,7 +174,7 @@ __device__ __forceinline__ RowParams ring_load_row_params(const GemmArgs& a, int
     }
     return r;
 }
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16, bool FP = false>
 __device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t* smem, int tid_in = -1) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     static_assert(BM <= NT, "one token row per thread");
@@ -176,8 +183,13 @@ __device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t
     const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     if (tx < BM) {
         reinterpret_cast<float*>(smem + ROW_OFF)[tx] = r.sx;
-        reinterpret_cast<int*>(smem + ROW_OFF)[BM + tx] = r.nzx;
-        reinterpret_cast<int*>(smem + ROW_OFF)[2 * BM + tx] = r.R;
+        if constexpr (FP) {
+            reinterpret_cast<float*>(smem + ROW_OFF)[BM + tx] = r.sx * (float)r.nzx;
+            reinterpret_cast<float*>(smem + ROW_OFF)[2 * BM + tx] = r.sx * (float)r.R;
+        } else {
+            reinterpret_cast<int*>(smem + ROW_OFF)[BM + tx] = r.nzx;
+            reinterpret_cast<int*>(smem + ROW_OFF)[2 * BM + tx] = r.R;
+        }
     }
 }
 
@@ -216,7 +228,33 @@ __device__ __forceinline__ void ring_stage_params(const GemmArgs& a, uint8_t* sm
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16>
+// One output of the dequantisation, y = sx sw (acc - zw R - zx cs) + b.
+//   FP = false: the correction exact in int32 - two v_mad_i32_i24 (|zw|, |zx| < 2^8, |R|, |cs| < 2^23; written as asm
+//               because the compiler otherwise emits 2 x v_mul_i32_i24 + v_add3_u32), one conversion, mul + fma;
+//   FP = true:  nzx / Rm / nzw / ics carry the BIT PATTERNS of the parked fp32 products V = sx (-zx), U = sx R,
+//               P = sw (-zw), Q = sw cs: y = (sx sw) float(acc) + (U P + (V Q + b)) - the compiler packs the four
+//               operations of neighbouring outputs into v_pk_mul_f32 / v_pk_fma_f32.
+template <bool FP>
+__device__ __forceinline__ float ring_dequant(int acc, float sx, int nzx, int Rm, float sw, int nzw, int ics, float b) {
+    if constexpr (FP) {
+        const float V = __builtin_bit_cast(float, nzx), U = __builtin_bit_cast(float, Rm);
+        const float P = __builtin_bit_cast(float, nzw), Q = __builtin_bit_cast(float, ics);
+        return __builtin_fmaf(sx * sw, (float)acc, __builtin_fmaf(U, P, __builtin_fmaf(V, Q, b)));
+    } else {
+        int t1, tt;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(nzw), "v"(Rm), "v"(acc));
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(tt) : "v"(nzx), "v"(ics), "v"(t1));
+        return (sx * sw) * (float)tt + b;
+    }
+}
+
+// FP: the dequantisation in floating point - y = (sx sw) acc + U P + V Q + b with the parked products (ring_park_*<FP>):
+// 1 conversion + 4 packed fp32 operations per PAIR of outputs instead of 2 x (2 v_mad_i32_i24 + conversion) + 2 packed
+// ones: 3.5 instead of 4.5 VALU issue slots per output in a phase that is VALU-bound (144 outputs per lane, 4 cycles per
+// wave-instruction, two waves per SIMD = the 6.5 k cycles the stamps show).  The integer form is exact; this one rounds
+// the three products separately - the terms are up to ~50 x the result, so outputs move by <= 2e-5 relative, 1/25 of
+// the fp16 rounding that follows (rel-L2 vs the fp32 reference unchanged, asserted by the GEMM tests).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16, bool FP = false>
 __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_t* smem,
                                                        int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
                                                        int tid) {
@@ -263,7 +301,7 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
         pgo += w ? step_g + wrap_g : step_g;
     };
     float sxm[TM];
-    int nzx[TM], Rm[TM];
+    int nzx[TM], Rm[TM];                              // (FP: the bit patterns of V = sx * (-zx) and U = sx * R)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int rl = wm * WTM + i * 16 + frow;
@@ -287,10 +325,7 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int t1, tt;                        // acc - zw*R - zx*cs, exact in int32 (see ring_epilogue)
-                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(nzw[e]), "v"(Rm[i]), "v"(acc[j][i][e]));
-                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(tt) : "v"(nzx[i]), "v"(ics[e]), "v"(t1));
-                    float y = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
+                    float y = ring_dequant<FP>(acc[j][i][e], sxm[i], nzx[i], Rm[i], fsw_[e], nzw[e], ics[e], fb[e]);
                     if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
                     o[e] = (half_t)y;
                 }
@@ -328,7 +363,7 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
 
 // Shared epilogue of the LDS-DMA ring kernels (called after a workgroup barrier; uses all of smem; the
 // parameter block must have been staged by ring_stage_params and made visible by that barrier).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16, bool FP = false>
 __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                                               int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
                                               long long* ts = nullptr, int tid_in = -1, bool gate_folded = false) {
@@ -344,7 +379,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
         const bool interior = m0 + BM <= a.M && n0 + BN <= a.N && (a.N & 7) == 0 && (a.ldo & 7) == 0 &&
                               (EPI != VQ_EPI_GATE_RESID || gate_folded);
         if (!ts && interior) {
-            ring_epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, PAD>(a, smem, acc, m0, n0, tid);
+            ring_epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, PAD, FP>(a, smem, acc, m0, n0, tid);
             return;
         }
     }
@@ -416,12 +451,7 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    // acc - zw*R - zx*cs, exact in int32: two v_mad_i32_i24 (|zw|,|zx| < 2^8, |R|,|cs| < 2^23);
-                    // written as asm because the compiler otherwise emits 2 x v_mul_i32_i24 + v_add3_u32
-                    int t1, tt;
-                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(nzw[e]), "v"(Rm[i]), "v"(acc[j][i][e]));
-                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(tt) : "v"(nzx[i]), "v"(ics[e]), "v"(t1));
-                    float y = (sxm[i] * fsw_[e]) * (float)tt + fb[e];
+                    float y = ring_dequant<FP>(acc[j][i][e], sxm[i], nzx[i], Rm[i], fsw_[e], nzw[e], ics[e], fb[e]);
                     if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
                     o[e] = (half_t)y;
                 }

@@ -3,6 +3,12 @@
 #pragma once
 #include "gemm_common.h"
 
+// dequantisation of the ring kernel's epilogue: 1 = packed fp32 form (gemm_common.h: ring_dequant<true>), 0 = the exact
+// integer correction (the form of rounds 1-3; kept for A/B builds: -DVQ_GEMM_FP_DEQUANT=0)
+#ifndef VQ_GEMM_FP_DEQUANT
+#define VQ_GEMM_FP_DEQUANT true
+#endif
+
 // ---------------------------------------------------------------------------
 // Full-line ring kernel (variant 11).  tools/dma_depth.py: the L2 -> LDS fill rate of a CU is bound by
 // cache-line REQUESTS, not bytes: 64-byte row chunks (BK 64) stream at 65 GB/s per CU, 128-byte
@@ -243,10 +249,10 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     const auto colp = ring_load_col_params<BN, 64 * NW>(a, n0, tid, gate_row);
     const RowParams rowp = ring_load_row_params<BM>(a, m0, tid);
     if constexpr (PAR_IN_RING) __syncthreads();
-    ring_park_col_params<BM, BN, WAVES_M, WAVES_N>(colp, smem, tid);
-    ring_park_row_params<BM, BN, WAVES_M, WAVES_N>(rowp, smem, tid);
+    ring_park_col_params<BM, BN, WAVES_M, WAVES_N, 16, VQ_GEMM_FP_DEQUANT>(colp, smem, tid);
+    ring_park_row_params<BM, BN, WAVES_M, WAVES_N, 16, VQ_GEMM_FP_DEQUANT>(rowp, smem, tid);
     __syncthreads();
-    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI>(a, smem, acc, m0, n0, ts, tid, gate_row != nullptr);
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI, 16, VQ_GEMM_FP_DEQUANT>(a, smem, acc, m0, n0, ts, tid, gate_row != nullptr);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>

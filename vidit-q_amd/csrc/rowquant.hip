@@ -457,6 +457,8 @@ extern "C" int vq_rowquant(const void* x, const void* add_rows, int n_add, int a
 
 bool vq_gelu_rowquant_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
                            int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
+bool vq_gelu_rowquant_pair_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
+                                int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
 
 extern "C" int vq_gelu_rowquant(const void* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
                                 int32_t* R, int B, int n_tok, int C, int Kp, int n_bits, int32_t* status, void* stream) {
@@ -464,7 +466,13 @@ extern "C" int vq_gelu_rowquant(const void* x, const float* s, const float* s_rc
     if (B <= 0 || n_tok <= 0 || C <= 0) return VQ_EINVAL;
     if (C % 8 != 0 || Kp % 128 != 0 || Kp < C) return VQ_ESHAPE;
     if (n_bits < 2 || n_bits > 8) return VQ_EUNSUP;
-    if (B != 1) return VQ_EUNSUP;   // batch-shared token scales: use the GEMM's GELU epilogue + vq_rowquant
+    if (B > 2) return VQ_EUNSUP;    // larger batches with shared token scales: use the GEMM's GELU epilogue + vq_rowquant
+    if (B == 2) {                   // uncond | cond pair, grids shared over the two samples of a token
+        if (!vq_gelu_rowquant_pair_fast((const half_t*)x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status,
+                                        (hipStream_t)stream))
+            return VQ_EUNSUP;
+        return vq_check_launch();
+    }
     if (!vq_gelu_rowquant_fast((const half_t*)x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
         return VQ_ESHAPE;
     return vq_check_launch();

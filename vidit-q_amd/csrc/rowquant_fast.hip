@@ -11,6 +11,7 @@
 //   - LN + modulate keeps the modulated row in fp32 registers between the min/max and the
 //     quantize pass and reads shift/scale as 16-byte vectors.
 // HBM-bound: algorithmic bytes per row = 2*C read + Kp written.
+#include <stdlib.h>
 #include "vq_common.h"
 
 #define RQF_WAVES 4
@@ -1145,6 +1146,27 @@ bool vq_gelu_rowquant_fast(const half_t* x, const float* s, const float* s_rcp, 
     else if (Kp <= 1536) { if (s) RQG_GO(3, true); else RQG_GO(3, false); }
     else { if (s) RQG_GO(9, true); else RQG_GO(9, false); }
 #undef RQG_GO
+    return true;
+}
+
+// The same for a batch of TWO whose token grids the reference shares over the batch (the t2i loop's uncond | cond forward:
+// x [2, n_tok, C], base_quantizer.py:185): partner waves take the two samples of a token and combine their min / max
+// (after the GELU), as vq_rowquant's pair kernels do.
+bool vq_gelu_rowquant_pair_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
+                                int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+    if (C > 4608 || Kp > 4608 || n_tok < 1) return false;
+    if (s)
+        return s_rcp && C > 1536 && n_tok >= 2 &&
+               launch_rq_smooth_lds<true, true>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st);
+    dim3 grid((n_tok + RQF_WAVES / 2 - 1) / (RQF_WAVES / 2)), block(RQF_THREADS);
+#define RQGP_GO(M_)                                                                                                  \
+    hipLaunchKernelGGL((rowquant_fast_kernel<M_, false, false, true, true>), grid, block, 0, st, x, (const half_t*)nullptr, \
+                       1, (const float*)nullptr, (const float*)nullptr, xq, sx, zx, R, (float*)nullptr, n_tok, C, Kp, n_bits, \
+                       status)
+    if (Kp <= 512) RQGP_GO(1);
+    else if (Kp <= 1536) RQGP_GO(3);
+    else RQGP_GO(9);
+#undef RQGP_GO
     return true;
 }
 

@@ -186,15 +186,17 @@ def rowquant_multi(x: torch.Tensor, smooth: Sequence[torch.Tensor], n_bits: int 
 
 def gelu_rowquant(x: torch.Tensor, n_bits: int = 8, s: Optional[torch.Tensor] = None,
                   status: Optional[torch.Tensor] = None, fast_div: bool = True) -> QAct:
-    """GELU(tanh) then the per-token quantizer of x [1, n_tok, C] fp16 (the fc1 -> act -> fc2-quantizer hand-over)."""
+    """GELU(tanh) then the per-token quantizer of x [B, n_tok, C] fp16 (the fc1 -> act -> fc2-quantizer hand-over);
+    B = 1, or B = 2 with the grid of a token shared by its two samples (rows = sample * n_tok + token)."""
     _req(x, torch.float16, "x")
     B, n_tok, Cc = x.shape
     Kp = pad128(Cc)
     dev = x.device
-    xq = torch.empty((n_tok, Kp), dtype=torch.int8, device=dev)
-    sx = torch.empty(n_tok, dtype=torch.float32, device=dev)
-    zx = torch.empty(n_tok, dtype=torch.int32, device=dev)
-    R = torch.empty(n_tok, dtype=torch.int32, device=dev)
+    rows = B * n_tok
+    xq = torch.empty((rows, Kp), dtype=torch.int8, device=dev)
+    sx = torch.empty(rows, dtype=torch.float32, device=dev)
+    zx = torch.empty(rows, dtype=torch.int32, device=dev)
+    R = torch.empty(rows, dtype=torch.int32, device=dev)
     if s is not None:
         _req(s, torch.float32, "s")
     s_rcp = smooth_rcp(s) if fast_div else None

@@ -281,11 +281,19 @@ class QuantLayer(nn.Module):
         return ops.rowquant(x3, n_bits=aq.n_bits, s=s, add_rows=add_rows, add_div=add_div,
                             delta=aq.delta.float(), zp=aq.zero_point.float())
 
+    def gelu_one_pass_ok(self, B: int, K: int, s: Optional[torch.Tensor]) -> bool:
+        """Whether :meth:`quantize_gelu_input` covers a [B, n, K] input (decided BEFORE the producing GEMM is launched: it
+        picks that GEMM's epilogue)."""
+        if not isinstance(self.act_quantizer, DynamicActQuantizer):
+            return False
+        return B == 1 or (B == 2 and (s is None or K > 1536))
+
     def quantize_gelu_input(self, h3: torch.Tensor, s: Optional[torch.Tensor]) -> Optional[ops.QAct]:
-        """act(GELU tanh) + this layer's activation quantizer in one pass over the PRE-activation ``h3`` [1, n, K];
-        None when the one-pass kernel does not apply (batch-shared scales, static grids): the caller then asks the
-        producing GEMM for its GELU epilogue and calls :meth:`quantize_input`."""
-        if h3.shape[0] != 1 or not isinstance(self.act_quantizer, DynamicActQuantizer):
+        """act(GELU tanh) + this layer's activation quantizer in one pass over the PRE-activation ``h3`` [B, n, K], B = 1
+        or the uncond | cond pair B = 2 (token grids shared over the pair); None when the one-pass kernel does not apply
+        (larger batches, static grids): the caller then asks the producing GEMM for its GELU epilogue and calls
+        :meth:`quantize_input`."""
+        if not self.gelu_one_pass_ok(h3.shape[0], h3.shape[-1], s):
             return None
         return ops.gelu_rowquant(h3, n_bits=self.act_quantizer.n_bits, s=s, status=self.status)
 

@@ -175,9 +175,11 @@ class PixArtMSBlock(nn.Module):
         r, s = sv(fc1)
         qa = STDiTBlock._ln_quant(x3, shift_mlp, scale_mlp, (fc1,), [s], st)[0]
         from ..t2v.stdit import _GELU_QUANT
-        one_pass = _GELU_QUANT and B == 1 and isinstance(fc2.act_quantizer, DynamicActQuantizer)   # see t2v/stdit.py
+        r2, s2 = sv(fc2)
+        # GELU inside fc2's quantizer pass (see t2v/stdit.py), also for the uncond | cond pair of the t2i loop
+        one_pass = _GELU_QUANT and fc2.gelu_one_pass_ok(B, fc2.in_features, s2)
         h = ops.gemm_i8(qa, fc1.packed_weight(r, s), bias=fc1.bias_f32(), epilogue=ops.EPI_NONE if one_pass else ops.EPI_GELU)
-        r, s = sv(fc2)
+        r, s = r2, s2
         qa = fc2.quantize_gelu_input(h.view(B, N, -1), s) if one_pass else fc2.quantize_input(h.view(B, N, -1), s)
         ops.gemm_i8(qa, fc2.packed_weight(r, s), bias=fc2.bias_f32(), out=x2,
                     epilogue=ops.EPI_GATE_RESID, resid=x2, gate=gate_mlp, rows_per_gate=N)

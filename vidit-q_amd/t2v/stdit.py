@@ -513,7 +513,7 @@ class STDiTBlock(nn.Module):
         # ---- MLP: x += gate_mlp * fc2(gelu(fc1(LN-mod(x))))                   (stdit.py:124-128)
         fc1, fc2 = self.mlp.fc1, self.mlp.fc2
         qa = self._ln_quant(x3, shift_mlp, scale_mlp, (fc1,), [svec(fc1)], st)[0]
-        one_pass = B == 1 and isinstance(fc2.act_quantizer, DynamicActQuantizer) and _GELU_QUANT
+        one_pass = _GELU_QUANT and fc2.gelu_one_pass_ok(B, fc2.in_features, svec(fc2))
         h = ops.gemm_i8(qa, fc1.packed_weight(r, svec(fc1)), bias=fc1.bias_f32(),
                         epilogue=ops.EPI_NONE if one_pass else ops.EPI_GELU)
         qa = fc2.quantize_gelu_input(h.view(B, N, -1), svec(fc2)) if one_pass else fc2.quantize_input(h.view(B, N, -1), svec(fc2))
