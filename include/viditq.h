@@ -259,6 +259,19 @@ int vq_cfg_ddim_step(const float* cond, const float* uncond, const float* x, flo
                      int n, int C, int inner, float cfg, float one_plus_k,
                      float A, float Bc, float abar_prev, void* stream);
 
+/* ---- floating-point Linears at the edges of a forward -------------------------------------
+ * out[m, n] = act_out( sum_k act_in(x[m, k]) * w[n, k] + bias[n] ): fp16 operands and result, fp32 accumulation (MFMA),
+ * act: 0 none, 1 SiLU, 2 GELU(tanh).  Replaces F.linear of the layers the reference's FP lists keep out of quantization
+ * (t2v/remain_fp.txt; quant_txt2img.py:294): TimestepEmbedder.mlp = Linear, SiLU, Linear
+ * (t2v/opensora/models/layers/blocks.py:405-460; act_out = 1 on the first), t_block = SiLU, Linear
+ * (t2v/opensora/models/stdit/stdit.py:193-196; act_in = 1), CaptionEmbedder.y_proj = Linear, GELU(tanh), Linear
+ * (blocks.py:511-548; act_out = 2 on the first), T2IFinalLayer.linear (blocks.py:393-397), and the patch embedding
+ * PatchEmbed3D.proj, a Conv3d whose kernel equals its stride, as a [tokens, C_in pt ph pw] matmul (blocks.py:66-105).
+ * x [M, K] row pitch ldx, w [N, K] row pitch ldw, bias [N] fp16 or NULL, out [M, N] row pitch ldo (elements).
+ * K % 8 == 0, N % 4 == 0, pitches multiples of 8 / 8 / 4.  Supported (act_in, act_out): (0,0) (0,1) (0,2) (1,0). */
+int vq_linear_f16(const void* x, const void* w, const void* bias, void* out, int M, int N, int K, long ldx, long ldw,
+                  long ldo, int act_in, int act_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -892,3 +892,36 @@ def test_gemm_interior_epilogue_is_bit_identical_to_general_path(ops, dev, epi, 
     assert torch.equal(fast, slow)
     assert torch.all(wide[:, N:] == 0)
 
+
+
+@pytest.mark.parametrize("M,N,K,act_in,act_out", [
+    (1, 1152, 256, 0, 1),        # t_embedder.mlp.0 + SiLU
+    (2, 1152, 1152, 0, 0),       # t_embedder.mlp.2 (a batch of two)
+    (2, 6912, 1152, 1, 0),       # t_block: SiLU, Linear
+    (120, 1152, 4096, 0, 2),     # y_embedder.y_proj.fc1 + GELU(tanh)
+    (600, 1152, 1152, 0, 0),     # y_embedder.y_proj.fc2 at 2 x 300 PixArt-Sigma prompt tokens
+    (16384, 32, 1152, 0, 0),     # final_layer.linear
+    (16384, 1152, 16, 0, 0),     # patch embedding as a matmul (K = 16: one half-filled k-step)
+    (77, 36, 72, 0, 2),          # ragged everything
+])
+def test_fp_edge_linear_against_fp32(ops, dev, M, N, K, act_in, act_out):
+    """vq_linear_f16 (the FP Linears at the edges of a forward) against the oracle's FP route - F.linear in fp32 on the
+    same fp16 operands, activations in fp32: one fp16 rounding of the result apart (rel-L2 < 4e-4; every element within
+    2 fp16 ulps + the fp32 summation-order noise of a K-long dot product)."""
+    import torch.nn.functional as F
+    x = h16(M, K, scale=1.0, seed=M + K).to(dev)
+    w = h16(N, K, scale=(2.0 / (N + K)) ** 0.5 * 3, seed=N + K + 1).to(dev)
+    b = h16(N, scale=0.1, seed=7).to(dev)
+    out = ops.linear_f16(x, w, b, act_in=act_in, act_out=act_out).float().cpu()
+    act = {0: lambda v: v, 1: F.silu, 2: lambda v: F.gelu(v, approximate="tanh")}
+    # the kernel rounds act_in(x) to fp16 before the contraction, as the reference's fp16 module chain does
+    xin = act[act_in](x.float().cpu()).half().float() if act_in else x.float().cpu()
+    ref = act[act_out](F.linear(xin, w.float().cpu(), b.float().cpu()))
+    assert out.shape == (M, N)
+    assert rel_l2(out, ref) < 4e-4
+    tol = 2 * 2.0 ** -10 * ref.abs().clamp(min=2.0 ** -14) + 1e-5 * K ** 0.5
+    assert bool(((out - ref).abs() <= tol).all())
+    # no bias, strided input rows
+    xs = h16(M, K + 8, scale=1.0, seed=3).to(dev)[:, :K]
+    o2 = ops.linear_f16(xs.contiguous(), w, None).float().cpu()
+    assert rel_l2(o2, F.linear(xs.float().cpu(), w.float().cpu())) < 4e-4

@@ -44,6 +44,7 @@ SIGNATURES = {
     "vq_attn_temporal_rowquant": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _i, _f,
                                        _vp]),
     "vq_adaln_table": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vq_linear_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _vp]),
     "vq_cfg_ddim_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
 }
 

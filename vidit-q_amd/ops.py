@@ -534,6 +534,31 @@ def adaln_table(table: torch.Tensor, t0: torch.Tensor) -> torch.Tensor:
     return mod
 
 
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+
+def linear_f16(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act_in: int = ACT_NONE,
+               act_out: int = ACT_NONE) -> torch.Tensor:
+    """act_out(act_in(x) @ w.T + bias) for the FP edge Linears (embedders, t_block, final layer, patch embedding as a
+    matmul): x [..., K] fp16 (last dim contiguous), w [N, K] fp16, bias [N] fp16; fp32 accumulation, fp16 result."""
+    _req(x, torch.float16, "x")
+    _req(w, torch.float16, "w")
+    K = x.shape[-1]
+    N = w.shape[0]
+    assert w.dim() == 2 and w.shape[1] == K and w.stride(1) == 1
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    if bias is not None:
+        _req(bias, torch.float16, "bias")
+        assert bias.numel() == N and bias.is_contiguous()
+    M = x2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    check(_L().vq_linear_f16(_p(x2), _p(w), _p(bias), _p(out), M, N, K, x2.stride(0), w.stride(0), N, act_in, act_out,
+                             _stream()), "vq_linear_f16")
+    return out.reshape(*x.shape[:-1], N)
+
+
 def cfg_ddim_step(cond: torch.Tensor, uncond: torch.Tensor, x: torch.Tensor, cfg: float, one_plus_k: float,
                   A: float, Bc: float, abar_prev: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(cond, torch.float32, "cond")

@@ -25,7 +25,7 @@ from .. import ops
 from ..qdiff.models.quant_block import QuantAttention
 from ..qdiff.models.quant_layer import QuantLayer
 from ..qdiff.quantizer.dynamic_quantizer import DynamicActQuantizer
-from ..t2v.stdit import (CaptionEmbedder, Mlp, MultiHeadCrossAttention, STDiTBlock, T2IFinalLayer, TimestepEmbedder,
+from ..t2v.stdit import (CaptionEmbedder, Mlp, fp_edge_linear, MultiHeadCrossAttention, STDiTBlock, T2IFinalLayer, TimestepEmbedder,
                          approx_gelu, get_1d_sincos_pos_embed_from_grid, seq_offsets, t2i_modulate)
 
 
@@ -333,7 +333,9 @@ class PixArt(_PixArtBase):
         self.h, self.w = x.shape[-2] // self.patch_size, x.shape[-1] // self.patch_size
         x = self.x_embedder(x) + self.pos_embed.to(self.dtype)
         t = self.t_embedder(timestep, dtype=x.dtype)
-        t0 = self.t_block(t)
+        t0 = fp_edge_linear(self.t_block[1], t, act_in=ops.ACT_SILU)        # SiLU, Linear in one launch (FP edge kernel)
+        if t0 is None:
+            t0 = self.t_block(t)
         y = self.y_embedder(y, self.training)
         y, y_lens = self._select(y, mask, C)
         x = self._run_blocks(x, y, t0, y_lens)
@@ -399,7 +401,9 @@ class PixArtMS(_PixArtBase):
         if self.micro_conditioning:
             c_size, ar = data_info["img_hw"].to(self.dtype), data_info["aspect_ratio"].to(self.dtype)
             t = t + torch.cat([self.csize_embedder(c_size, bs), self.ar_embedder(ar, bs)], dim=1)
-        t0 = self.t_block(t)
+        t0 = fp_edge_linear(self.t_block[1], t, act_in=ops.ACT_SILU)        # SiLU, Linear in one launch (FP edge kernel)
+        if t0 is None:
+            t0 = self.t_block(t)
         y = self.y_embedder(y, self.training)
         y, y_lens = self._select(y, mask, C)
         x = self._run_blocks(x, y, t0, y_lens)

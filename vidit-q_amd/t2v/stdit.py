@@ -68,6 +68,25 @@ def get_2d_sincos_pos_embed(embed_dim, grid_size, scale=1.0, base_size=None):
 
 
 # --------------------------------------------------------------------------- small modules
+def fp_edge_linear(layer, x, act_in=0, act_out=0):
+    """One of the Linears the FP lists keep in floating point (embedders, t_block, final layer: SURVEY 8 row F4), through
+    the HIP kernel vq_linear_f16 with its neighbouring activation fused - when it is a Linear in FP state on fp16 GPU
+    tensors; returns None otherwise (quantized by a non-default FP list, CPU, fp32: the caller takes the module path)."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float16):
+        return None
+    if isinstance(layer, nn.Linear):
+        w, b = layer.weight, layer.bias
+    else:
+        if getattr(layer, "fwd_func", None) is not F.linear or getattr(layer, "weight_quant", False) or (
+                getattr(layer, "act_quant", False) and not getattr(layer, "disable_act_quant", False)) or getattr(
+                layer, "smooth_quant", False) or getattr(layer, "smooth_quant_running_stat", False):
+            return None
+        w, b = layer.org_weight, layer.org_bias
+    if w.dtype != torch.float16 or w.numel() == 0 or w.shape[1] % 8 or w.shape[0] % 4 or (b is not None and b.dtype != torch.float16):
+        return None
+    return ops.linear_f16(x.contiguous(), w.detach(), None if b is None else b.detach(), act_in=act_in, act_out=act_out)
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=approx_gelu, bias=True, drop=0.0):
         super().__init__()
@@ -78,6 +97,13 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
 
     def forward(self, x):
+        # FP state (the caption embedder under every shipped FP list): two launches of the edge kernel, GELU fused
+        if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "tanh":
+            h = fp_edge_linear(self.fc1, x, act_out=ops.ACT_GELU)
+            if h is not None:
+                o = fp_edge_linear(self.fc2, h)
+                if o is not None:
+                    return o
         return self.fc2(self.act(self.fc1(x)))
 
 
@@ -110,7 +136,11 @@ class PatchEmbed3D(nn.Module):
             pt, ph, pw = self.patch_size
             xp = x.reshape(B, Cin, D // pt, pt, H // ph, ph, W // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
             xp = xp.reshape(B * (D // pt) * (H // ph) * (W // pw), Cin * pt * ph * pw)
-            out = F.linear(xp.to(w_.dtype), w_.reshape(w_.shape[0], -1), None if b_ is None else b_.to(w_.dtype))
+            w2 = w_.reshape(w_.shape[0], -1)
+            if w_.dtype == torch.float16 and w2.shape[1] % 8 == 0 and w2.shape[0] % 4 == 0:
+                out = ops.linear_f16(xp.to(w_.dtype).contiguous(), w2.detach(), None if b_ is None else b_.detach().to(w_.dtype))
+            else:
+                out = F.linear(xp.to(w_.dtype), w2, None if b_ is None else b_.to(w_.dtype))
             return out.reshape(B, -1, w_.shape[0])
         x = self.proj(x)
         return x.flatten(2).transpose(1, 2)  # BCTHW -> BNC
@@ -143,6 +173,11 @@ class TimestepEmbedder(nn.Module):
         t_freq = self.timestep_embedding(t, self.frequency_embedding_size)
         if t_freq.dtype != dtype:
             t_freq = t_freq.to(dtype)
+        h = fp_edge_linear(self.mlp[0], t_freq, act_out=ops.ACT_SILU)      # Linear, SiLU fused
+        if h is not None:
+            o = fp_edge_linear(self.mlp[2], h)
+            if o is not None:
+                return o
         return self.mlp(t_freq)
 
 
@@ -172,7 +207,8 @@ class T2IFinalLayer(nn.Module):
             # also produces are not used here) instead of a LayerNorm and two broadcast elementwise launches
             mod = ops.adaln_table(self.scale_shift_table.detach(), torch.cat([t, t], dim=1).to(torch.float16).contiguous())
             _, xm = ops.ln_modulate_rowquant(x.contiguous(), mod[0], mod[1], 1e-6, want_xm=True)
-            return self.linear(xm)
+            o = fp_edge_linear(self.linear, xm)                              # FP under the t2v list; quantized in t2i
+            return o if o is not None else self.linear(xm)
         shift, scale = (self.scale_shift_table[None] + t[:, None]).chunk(2, dim=1)
         x = t2i_modulate(self.norm_final(x), shift, scale)
         return self.linear(x)
@@ -716,7 +752,9 @@ class STDiT(nn.Module):
         x = x.reshape(B, self.num_temporal, self.num_spatial, C) + self.pos_embed
         x = x.reshape(B, self.num_patches, C).contiguous()
         t = self.t_embedder(timestep, dtype=x.dtype)
-        t0 = self.t_block(t)
+        t0 = fp_edge_linear(self.t_block[1], t, act_in=ops.ACT_SILU)        # SiLU, Linear in one launch
+        if t0 is None:
+            t0 = self.t_block(t)
         y, y_lens, off = self._prompt_tokens(y, mask, C)
 
         fused = x.is_cuda and x.dtype == torch.float16 and all(b.fused_ok() for b in self.blocks)
