@@ -84,6 +84,12 @@ def fp_edge_linear(layer, x, act_in=0, act_out=0):
         w, b = layer.org_weight, layer.org_bias
     if w.dtype != torch.float16 or w.numel() == 0 or w.shape[1] % 8 or w.shape[0] % 4 or (b is not None and b.dtype != torch.float16):
         return None
+    # the edge kernel is built for SKINNY problems (one 16 x 16 output tile per workgroup, no operand reuse): few rows, few
+    # columns or a short contraction.  A full-size FP Linear (16384 x 4608 x 1152: the block MLP of an FP calibration
+    # pass) stays with the vendor GEMM - it is not part of the quantized hot path.
+    M = x.numel() // x.shape[-1]
+    if not (M <= 640 or w.shape[0] <= 64 or w.shape[1] <= 32):
+        return None
     return ops.linear_f16(x.contiguous(), w.detach(), None if b is None else b.detach(), act_in=act_in, act_out=act_out)
 
 
