@@ -246,6 +246,9 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     // last MFMAs (wrong columns in rows of the slower waves; found by test_gemm_low_bit_weights).  There the global
     // loads are issued first and the LDS writes wait for a workgroup barrier.
     constexpr bool PAR_IN_RING = NW * WTM * (WTN * 2 + 16) < 2 * STAGE;
+    // (requested here, behind the main loop.  Issued before the first DMA batch instead - 7 more VGPRs through the loop, no
+    //  load latency between the last MFMA and the epilogue - the step did not move: 24.27 vs 24.25 steps/s in an A/B on
+    //  one box, and one single-round shape ran 6 x slower back to back (189 vs 29 us); round 4, not kept)
     const auto colp = ring_load_col_params<BN, 64 * NW>(a, n0, tid, gate_row);
     const RowParams rowp = ring_load_row_params<BM>(a, m0, tid);
     if constexpr (PAR_IN_RING) __syncthreads();
