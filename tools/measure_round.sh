@@ -8,7 +8,7 @@
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 R=$PWD
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift || true
 O=$R/gpurun_out/$TAG
 mkdir -p $O

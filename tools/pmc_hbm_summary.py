@@ -42,11 +42,12 @@ for d, _ in sets.values():
 out = ["# %s - counters of the HBM-bound kernels inside the step (MI355X, gfx950)" % TAG, "",
        "Source: `tools/pmc_hbm.sh %s` = `rocprofv3 --pmc <one set per pass> --kernel-trace -- python bench.py --depth 4 --steps 1 "
        "--warmup 1 --no-graph` (eager launches: kernels run ALONE, serialised by the profiler; W8A8, 16384 tokens).  SQ_* cycle "
-       "counters are in quad-cycles summed over waves; shares are of SQ_WAVE_CYCLES.  `occ` = SQ_WAVE_CYCLES x 4 / (cycles x 1024 "
-       "SIMDs) = mean resident waves per SIMD over the kernel, with cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over "
-       "the 8 XCDs: `clk` = that / us is the shader clock it implies - 1.9-2.4 GHz confirms the reading).  Fabric bytes: FETCH_SIZE x 2 (gfx950 streaming-read calibration, "
+       "counters are in quad-cycles summed over waves; shares are of SQ_WAVE_CYCLES.  `occ` = SQ_WAVE_CYCLES x 4 / (us x 2100 x "
+       "1024 SIMDs) = mean resident waves per SIMD over the kernel's traced duration at an ASSUMED 2.1 GHz (`GUI/8/us` = "
+       "GRBM_GUI_ACTIVE / 8 XCDs / us is shown beside it: 2.1 for the 105 us attention kernel, above the 2.4 GHz maximum for the "
+       "short kernels - the counter keeps running around a dispatch, so it is not used as the clock).  Fabric bytes: FETCH_SIZE x 2 (gfx950 streaming-read calibration, "
        "MI355X_MICROARCH.md HBM section; KiB units -> bytes), WRITE_SIZE as counted." % TAG, ""]
-hdr = ("| kernel | launches | us (profiled) | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | ACTIVE VALU | clk GHz | ACTIVE LDS | occ (waves/SIMD) | "
+hdr = ("| kernel | launches | us (profiled) | WAIT_ANY | WAIT_INST_ANY | ACTIVE_INST_ANY | ACTIVE VALU | GUI/8/us | ACTIVE LDS | occ (waves/SIMD) | "
        "VALU / VMEM_RD / VMEM_WR / LDS / SALU insts per wave | fabric read MB | write MB | TB/s (fabric bytes / us) |")
 out += [hdr, "|" + "---|" * (hdr.count("|") - 1)]
 for pat, label in KERNELS:
@@ -68,7 +69,7 @@ for pat, label in KERNELS:
             label, pat, tmpl[:40], len(d1), us, sh("SQ_WAIT_ANY"), sh("SQ_WAIT_INST_ANY"), sh("SQ_ACTIVE_INST_ANY"),
             sh("SQ_ACTIVE_INST_VALU"), ("%.2f" % (gui / 8 / us / 1e3)) if gui == gui and us == us and us else "-", sh("SQ_ACTIVE_INST_LDS", s2) if False else
             (("%.2f" % (mean(s2.get("SQ_ACTIVE_INST_LDS", [])) / wc)) if wc == wc and wc else "-"),
-            (wc * 4 / (gui / 8 * 1024)) if gui == gui and gui else float("nan"),
+            (wc * 4 / (us * 2100.0 * 1024)) if us == us and us else float("nan"),
             per("SQ_INSTS_VALU"), per("SQ_INSTS_VMEM_RD"), per("SQ_INSTS_VMEM_WR"), per("SQ_INSTS_LDS"), per("SQ_INSTS_SALU"),
             rd, wr, (rd + wr) / us if us == us and us else float("nan")))
 txt = "\n".join(out) + "\n"

@@ -65,7 +65,8 @@ def short(k):
                  ("gemm_i8_wide_kernel<256, 288, 4, 2, 2", "GEMM + gate*y + resid (proj x2, fc2)"), ("gemm_i8_wide_kernel<256, 288, 4, 2, 3", "GEMM + resid (cross proj)"),
                  ("gemm_i8_wide_kernel<128, 288, 4, 2, 0", "GEMM 128-row tiles (prompt K/V of all 28 blocks, one launch)"),
                  ("attn_fwd32d_kernel", "spatial attention (flash, 1024 keys)"), ("attn_fwd8_kernel", "spatial attention, previous generation"), ("attn_temporal_quant", "temporal attention + proj quantizer"),
-                 ("attn_cross_reg", "cross attention (K/V^T in registers)"), ("ln_modulate_rowquant_half", "LN + modulate + quantizer C=1152"),
+                 ("attn_cross_reg", "cross attention (K/V^T in registers)"), ("attn_cross32", "cross attention (K/V resident in LDS)"),
+                 ("fp_linear_kernel", "FP edge Linears (embedders, t_block, final layer, patch embedding)"), ("ln_modulate_rowquant_half", "LN + modulate + quantizer C=1152"),
                  ("rowquant_half", "per-token quantizer C=1152"), ("rowquant_fast_kernelILi9", "per-token quantizer C=4608")):
         if a in k:
             return b
@@ -87,6 +88,7 @@ ALG = {
     "spatial attention (flash, 1024 keys)": (4 * 2 * M * 1152, 4.0 * 16 * 16 * 1024 * 1024 * 72, "f16"),
     "temporal attention + proj quantizer": (3 * 2 * M * 1152 + M * 1152, 4.0 * 1024 * 16 * 16 * 16 * 72, "hbm"),
     "cross attention (K/V^T in registers)": (2 * 2 * M * 1152, None, "hbm"),
+    "cross attention (K/V resident in LDS)": (2 * 2 * M * 1152, None, "hbm"),
     "LN + modulate + quantizer C=1152": (2 * M * 1152 + M * 1152, None, "hbm"),
     "per-token quantizer C=1152": (2 * M * 1152 + M * 1152, None, "hbm"),
     "per-token quantizer C=4608": (2 * M * 4608 + M * 4608, None, "hbm"),
