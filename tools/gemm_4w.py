@@ -1,5 +1,6 @@
-"""Four waves of 128 x 144 (tools/lab/gemm_4w.hip) against the product ring kernel (8 waves of 64 x 144): bit-identity,
-back-to-back times at the block's GEMM shapes, the 4-wave kernel's ablations and its per-wave cycle stamps.  GPU box only."""
+"""Four waves of 128 x 144 - or, with `--waves 12`, twelve of 64 x 96 - (tools/lab/gemm_4w.hip) against the product ring kernel
+(8 waves of 64 x 144): bit-identity, back-to-back times at the block's GEMM shapes, the lab kernel's ablations and its
+per-wave cycle stamps.  GPU box only."""
 import os
 import sys
 
@@ -11,6 +12,8 @@ from viditq_amd import ops
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
 import lab  # noqa: E402
 
+NWV = 12 if "--waves" in sys.argv and sys.argv[sys.argv.index("--waves") + 1] == "12" else 4
+VARIANTS = (0,) if NWV == 12 else (0, 1)
 dev = torch.device("cuda:0")
 M = 16384
 g = torch.Generator().manual_seed(0)
@@ -44,19 +47,19 @@ for N, K, epi, name in SHAPES:
         kw.update(resid=res, gate=gate, rows_per_gate=M)
     ref = ops.gemm_i8(qa, pw, variant=11, **kw)
     line = "%-10s N %4d K %4d: ring(11) %6.1f us" % (name, N, K, timeit(lambda: ops.gemm_i8(qa, pw, variant=11, **kw)))
-    for v in (0, 1):
-        out = lab.gemm_4w(qa, pw, variant=v, **kw)
+    for v in VARIANTS:
+        out = lab.gemm_4w(qa, pw, variant=v, waves=NWV, **kw)
         same = torch.equal(out, ref)
-        line += " | 4w v%d %6.1f us %s" % (v, timeit(lambda: lab.gemm_4w(qa, pw, variant=v, **kw)), "bit-identical" if same else
+        line += " | %dw v%d %6.1f us %s" % (NWV, v, timeit(lambda: lab.gemm_4w(qa, pw, variant=v, waves=NWV, **kw)), "bit-identical" if same else
                                            "DIFFERS (max %g)" % float((out.float() - ref.float()).abs().max()))
     print(line, flush=True)
     if epi == ops.EPI_NONE:
-        print("    ablations of the 4-wave kernel (us): " + ", ".join(
-            "%s %.1f" % (nm, timeit(lambda: lab.gemm_4w(qa, pw, variant=v)))
+        print("    ablations of the %d-wave kernel (us): " % NWV + ", ".join(
+            "%s %.1f" % (nm, timeit(lambda: lab.gemm_4w(qa, pw, variant=v, waves=NWV)))
             for v, nm in ((101, "no DMA after prologue"), (108, "no fragment reads"), (109, "neither"), (102, "no MFMA"))), flush=True)
         tiles = (M // 256) * (N // 288)
         for nm, fn, nw in (("ring 8 waves", lambda st: lab.gemm_i8(qa, pw, variant=116, gate=st.view(torch.float32)), 8),
-                           ("4 waves", lambda st: lab.gemm_4w(qa, pw, variant=116, gate=st.view(torch.float32)), 4)):
+                           ("%d waves" % NWV, lambda st: lab.gemm_4w(qa, pw, variant=116, waves=NWV, gate=st.view(torch.float32)), NWV)):
             stamps = torch.zeros(tiles * nw * 10, dtype=torch.int64, device=dev)
             for _ in range(3):
                 fn(stamps)

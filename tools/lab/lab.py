@@ -28,6 +28,8 @@ def lib():
         _lib = C.CDLL(path)
         _lib.vq_lab_gemm_i8.restype = _i
         _lib.vq_lab_gemm_i8.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
+        _lib.vq_lab_gemm_12w.restype = _i
+        _lib.vq_lab_gemm_12w.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
         _lib.vq_lab_gemm_4w.restype = _i
         _lib.vq_lab_gemm_4w.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
         _lib.vq_probe_mfma_i8.argtypes = [_vp, _vp, _vp, _vp]
@@ -52,12 +54,13 @@ def gemm_i8(a, w, bias=None, out=None, epilogue=0, resid=None, gate=None, rows_p
     return out
 
 
-def gemm_4w(a, w, bias=None, out=None, epilogue=0, resid=None, gate=None, rows_per_gate=0, variant=0):
-    """tools/lab/gemm_4w.hip: the ring kernel with four waves of 128 x 144 (one per SIMD)"""
+def gemm_4w(a, w, bias=None, out=None, epilogue=0, resid=None, gate=None, rows_per_gate=0, variant=0, waves=4):
+    """tools/lab/gemm_4w.hip: the ring kernel with four waves of 128 x 144 (one per SIMD), or (waves=12) twelve of 64 x 96"""
     M, N = a.rows, w.N
     if out is None:
         out = torch.empty((M, N), dtype=torch.float16, device=a.xq.device)
-    rc = lib().vq_lab_gemm_4w(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs), _p(bias),
+    fn = lib().vq_lab_gemm_12w if waves == 12 else lib().vq_lab_gemm_4w
+    rc = fn(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs), _p(bias),
                               _p(out), out.stride(0), _p(resid), _p(gate), rows_per_gate, M, N, a.K, a.Kp, w.n_bits,
                               epilogue, variant, torch.cuda.current_stream().cuda_stream)
     if rc != 0:

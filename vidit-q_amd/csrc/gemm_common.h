@@ -132,11 +132,13 @@ __device__ __forceinline__ ColParamsT<(BN + NT - 1) / NT> ring_load_col_params(c
 }
 // FP (round 4): the zero-point terms are parked as fp32 PRODUCTS with the scale - P = sw * (-zw), Q = sw * cs per
 // channel, U = sx * R, V = sx * (-zx) per token - for the float form of the dequantisation (ring_dequant below).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16, bool FP = false, int NPT = 1>
+// SROWS: rows of a wave's epilogue slab when it is smaller than the wave tile (half slabs: the 12-wave lab kernel, whose full
+// slabs would not fit beside the parameter blocks); 0 = the whole wave tile.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16, bool FP = false, int SROWS = 0, int NPT = 1>
 __device__ __forceinline__ void ring_park_col_params(const ColParamsT<NPT>& c, uint8_t* smem, int tid_in = -1) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     static_assert(BN <= NPT * NT, "NPT channels per thread");
-    constexpr int PAR_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD);
+    constexpr int PAR_OFF = NW * (SROWS ? SROWS : BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD);
     const int tx0 = tid_in >= 0 ? tid_in : (int)threadIdx.x;
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
@@ -174,11 +176,11 @@ __device__ __forceinline__ RowParams ring_load_row_params(const GemmArgs& a, int
     }
     return r;
 }
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16, bool FP = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PAD = 16, bool FP = false, int SROWS = 0>
 __device__ __forceinline__ void ring_park_row_params(const RowParams& r, uint8_t* smem, int tid_in = -1) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     static_assert(BM <= NT, "one token row per thread");
-    constexpr int ROW_OFF = NW * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD) + 16 * BN;
+    constexpr int ROW_OFF = NW * (SROWS ? SROWS : BM / WAVES_M) * ((BN / WAVES_N) * 2 + PAD) + 16 * BN;
     static_assert(ROW_OFF + 12 * BM <= 163840, "LDS budget");
     const int tx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     if (tx < BM) {
@@ -254,14 +256,15 @@ __device__ __forceinline__ float ring_dequant(int acc, float sx, int nzx, int Rm
 // wave-instruction, two waves per SIMD = the 6.5 k cycles the stamps show).  The integer form is exact; this one rounds
 // the three products separately - the terms are up to ~50 x the result, so outputs move by <= 2e-5 relative, 1/25 of
 // the fp16 rounding that follows (rel-L2 vs the fp32 reference unchanged, asserted by the GEMM tests).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16, bool FP = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16, bool FP = false, int SROWS = 0>
 __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_t* smem,
                                                        int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
                                                        int tid) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int ROWB = WTN * 2 + PAD, SLAB = WTM * ROWB, PAR_OFF = NW * SLAB;
+    constexpr int ROWB = WTN * 2 + PAD, SLAB = (SROWS ? SROWS : WTM) * ROWB, PAR_OFF = NW * SLAB;
+    constexpr bool HALF_SLAB = SROWS != 0 && SROWS < WTM;   // the second half pass re-uses the slab rows of the first
     constexpr int CPR = WTN / 8, NCH = WTM * CPR, NITER = NCH / 64;
     constexpr int QS = 64 / CPR, RS = 64 % CPR;       // chunk c + 64: QS rows further (+1 on wrap), RS chunks to the right
     static_assert(NCH % 64 == 0 && CPR < 64, "whole passes");
@@ -290,6 +293,7 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
     // is dequantised, instead of all VALU work first and all stores after it.
     constexpr int NH = (TM % 2 == 0 && NITER % 2 == 0 && ((WTM / 2) * CPR) % 64 == 0) ? 2 : 1;
     constexpr int TMH = TM / NH, NITH = NITER / NH;
+    static_assert(!HALF_SLAB || (NH == 2 && SROWS == WTM / 2), "half slabs need the two half passes");
     // the residual operand: requested during the dequant phase (its HBM latency hides under the VALU work)
     half8 rres[HAS_RES ? NITH : 1];
     int pcc = cc0;
@@ -329,7 +333,7 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
                     if constexpr (EPI == VQ_EPI_GELU) y = gelu_tanh_f(y);
                     o[e] = (half_t)y;
                 }
-                *reinterpret_cast<half4*>(slab + (i * 16 + frow) * ROWB + (j * 16 + 4 * fc) * 2) = o;
+                *reinterpret_cast<half4*>(slab + ((HALF_SLAB ? i - h * TMH : i) * 16 + frow) * ROWB + (j * 16 + 4 * fc) * 2) = o;
             }
             if constexpr (HAS_RES) {
                 constexpr int PER = (NITH + TN - 1) / TN;
@@ -358,12 +362,13 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
             go += w ? step_g + wrap_g : step_g;
             so += w ? step_s + wrap_s : step_s;
         }
+        if constexpr (HALF_SLAB) so -= (uint32_t)((WTM / 2) * ROWB);   // (a half pass covers exactly WTM / 2 rows: cc is back at cc0)
     }
 }
 
 // Shared epilogue of the LDS-DMA ring kernels (called after a workgroup barrier; uses all of smem; the
 // parameter block must have been staged by ring_stage_params and made visible by that barrier).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16, bool FP = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16, bool FP = false, int SROWS = 0>
 __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                                               int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
                                               long long* ts = nullptr, int tid_in = -1, bool gate_folded = false) {
@@ -379,9 +384,12 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
         const bool interior = m0 + BM <= a.M && n0 + BN <= a.N && (a.N & 7) == 0 && (a.ldo & 7) == 0 &&
                               (EPI != VQ_EPI_GATE_RESID || gate_folded);
         if (!ts && interior) {
-            ring_epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, PAD, FP>(a, smem, acc, m0, n0, tid);
+            ring_epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, PAD, FP, SROWS>(a, smem, acc, m0, n0, tid);
             return;
         }
+    }
+    if constexpr (SROWS != 0 && SROWS < BM / WAVES_M) {   // half slabs exist for interior tiles only (lab kernels: the launcher checks)
+        __builtin_trap();
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;

@@ -36,6 +36,9 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     constexpr int BARJ = TN - 2;                      // after the last fragment read of the current stage
     constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (next tile)
     static_assert((TM == 8 || TM == 4 || TM == 2) && TN >= 3 && TN % 3 == 0, "fragment rings below");
+    // more than 8 waves: full epilogue slabs (NW x WTM rows) no longer fit beside the parameter blocks - half slabs
+    constexpr int SROWS = NW > 8 ? WTM / 2 : 0;
+    constexpr int SLROWS = SROWS ? SROWS : WTM;
     static_assert(BN * WROW % 1024 == 0 && STAGE % 128 == 0, "whole pieces, 128-byte aligned stages");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
 
@@ -245,17 +248,17 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     // number is even (K = 256, 4608): parked before every wave had left the loop it overwrote weight rows under the
     // last MFMAs (wrong columns in rows of the slower waves; found by test_gemm_low_bit_weights).  There the global
     // loads are issued first and the LDS writes wait for a workgroup barrier.
-    constexpr bool PAR_IN_RING = NW * WTM * (WTN * 2 + 16) < 2 * STAGE;
+    constexpr bool PAR_IN_RING = NW * SLROWS * (WTN * 2 + 16) < 2 * STAGE;
     // (requested here, behind the main loop.  Issued before the first DMA batch instead - 7 more VGPRs through the loop, no
     //  load latency between the last MFMA and the epilogue - the step did not move: 24.27 vs 24.25 steps/s in an A/B on
     //  one box, and one single-round shape ran 6 x slower back to back (189 vs 29 us); round 4, not kept)
     const auto colp = ring_load_col_params<BN, 64 * NW>(a, n0, tid, gate_row);
     const RowParams rowp = ring_load_row_params<BM>(a, m0, tid);
     if constexpr (PAR_IN_RING) __syncthreads();
-    ring_park_col_params<BM, BN, WAVES_M, WAVES_N, 16, VQ_GEMM_FP_DEQUANT>(colp, smem, tid);
-    ring_park_row_params<BM, BN, WAVES_M, WAVES_N, 16, VQ_GEMM_FP_DEQUANT>(rowp, smem, tid);
+    ring_park_col_params<BM, BN, WAVES_M, WAVES_N, 16, VQ_GEMM_FP_DEQUANT, SROWS>(colp, smem, tid);
+    ring_park_row_params<BM, BN, WAVES_M, WAVES_N, 16, VQ_GEMM_FP_DEQUANT, SROWS>(rowp, smem, tid);
     __syncthreads();
-    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI, 16, VQ_GEMM_FP_DEQUANT>(a, smem, acc, m0, n0, ts, tid, gate_row != nullptr);
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI, 16, VQ_GEMM_FP_DEQUANT, SROWS>(a, smem, acc, m0, n0, ts, tid, gate_row != nullptr);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>
