@@ -285,6 +285,33 @@ def test_gemm_half_height_tile_is_bit_identical(ops, dev, M, N, K, w_bits):
         assert torch.equal(ops.gemm_i8(qa, pw, bias=b, **kw), o11)
 
 
+@pytest.mark.parametrize("w_bits", [8, 4])
+@pytest.mark.parametrize("M,N,K", [(512, 576, 256), (1024, 1152, 1152), (768, 4608, 1152), (512, 1152, 4608), (256, 288, 128)])
+def test_gemm_twelve_wave_form_is_bit_identical(ops, dev, M, N, K, w_bits):
+    """The 12-wave form of the ring kernel (variant 18: 4 x 3 waves of 64 x 96, epilogue through half slabs; what the library
+    picks for the long launches, fc1 / fc2) computes every output with the arithmetic of the 8-wave form (variant 11): equal
+    bit for bit, every epilogue, W8 and W4, odd and even k-tile counts; shapes that are not made of interior tiles are
+    refused for the pinned variant and take the 8-wave form by default."""
+    x = h16(1, M, K, scale=1.5, seed=M + K).to(dev)
+    W = h16(N, K, scale=0.04, seed=N).to(dev)
+    b = h16(N, scale=0.1, seed=5).float().to(dev)
+    resid = h16(M, N, scale=1.0, seed=6).to(dev)
+    gate = h16(M // 256, N, scale=0.5, seed=7).float().to(dev)
+    qa = ops.rowquant(x)
+    d, z = ops.weight_minmax(W, w_bits)
+    pw = ops.pack_weight(W, d, z, w_bits)
+    for kw in (dict(epilogue=ops.EPI_NONE), dict(epilogue=ops.EPI_GELU), dict(epilogue=ops.EPI_RESID, resid=resid),
+               dict(epilogue=ops.EPI_GATE_RESID, resid=resid, gate=gate, rows_per_gate=256)):
+        o11 = ops.gemm_i8(qa, pw, bias=b, variant=11, **kw)
+        o18 = ops.gemm_i8(qa, pw, bias=b, variant=18, **kw)
+        assert torch.equal(o11, o18), kw["epilogue"]
+        assert torch.equal(ops.gemm_i8(qa, pw, bias=b, **kw), o11)
+    qr = ops.rowquant(h16(1, 300, K, scale=1.5, seed=1).to(dev))          # ragged: not interior
+    with pytest.raises(Exception):
+        ops.gemm_i8(qr, pw, bias=b, variant=18)
+    assert torch.equal(ops.gemm_i8(qr, pw, bias=b), ops.gemm_i8(qr, pw, bias=b, variant=11))
+
+
 def test_gemm_full_tile_property_linearity(ops, dev):
     """Full-size tile grid (M=16384): integer form must be exactly linear in the codes:
     doubling sx doubles (out - bias); checked against a torch fp32 matmul of the dequantized operands."""

@@ -58,6 +58,8 @@ for N, K, epi, name in SHAPES:
             "%s %.1f" % (nm, timeit(lambda: lab.gemm_4w(qa, pw, variant=v, waves=NWV)))
             for v, nm in ((101, "no DMA after prologue"), (108, "no fragment reads"), (109, "neither"), (102, "no MFMA"))), flush=True)
         tiles = (M // 256) * (N // 288)
+        if NWV == 12:        # the stamped build takes the general epilogue, which half slabs do not have (it traps)
+            continue
         for nm, fn, nw in (("ring 8 waves", lambda st: lab.gemm_i8(qa, pw, variant=116, gate=st.view(torch.float32)), 8),
                            ("%d waves" % NWV, lambda st: lab.gemm_4w(qa, pw, variant=116, waves=NWV, gate=st.view(torch.float32)), NWV)):
             stamps = torch.zeros(tiles * nw * 10, dtype=torch.int64, device=dev)

@@ -270,7 +270,8 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool 
 static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
-    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * (BM / WAVES_M) * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4 + 12 * BM;
+    constexpr int SLROWS = WAVES_M * WAVES_N > 8 ? BM / WAVES_M / 2 : BM / WAVES_M;      // half slabs beyond 8 waves (gemm_i8_wide_tile)
+    constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * SLROWS * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4 + 12 * BM;
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
