@@ -1220,12 +1220,25 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs 
                     pf[r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t[1]);
                 }
             }
+            if constexpr ((ABLD & 16) != 0) {
+                // profiling only: the 8 cross-lane moves per 32-key half (16 per tile) that a second lane layout of P^T would
+                // need for 16 x 16 x 32 MFMAs over dims 64..79: DPP moves of the P registers, results wrong
+                int4v* pw = reinterpret_cast<int4v*>(pf);
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2)
+                        pw[w2][e2] = __builtin_amdgcn_update_dpp(pw[w2][e2], pw[w2][e2], 0x141 /* row_half_mirror */, 0xf, 0xf, false);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int idx = 0; idx < 2 * C::DT; ++idx) {
                 rdc(C::KS + idx + PF);
                 const int dt = idx % C::DT;
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx].v, pf[idx / C::DT], oacc[dt], 0, 0, 0);
+                // ABLD & 8 (profiling only, results wrong): one of the two MFMAs of the LAST 32-dim tile dropped per half -
+                // the 64 matrix-pipe cycles per 64-key tile that 16 x 16 x 32 MFMAs over dims 64..79 would save
+                if (!((ABLD & 8) != 0 && dt == C::DT - 1 && idx / C::DT == 1))
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx].v, pf[idx / C::DT], oacc[dt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1268,7 +1281,8 @@ static int launch_attn32d(const AttnArgs& a, hipStream_t st) {
     if (D == 72 && NW == 8) {
         static const int abl = getenv("VQ_ATTN32_ABL") ? atoi(getenv("VQ_ATTN32_ABL")) : 0;
         if (abl) {
-            auto ka = abl == 1 ? attn_fwd32d_kernel<72, 1> : abl == 4 ? attn_fwd32d_kernel<72, 4> : attn_fwd32d_kernel<72, 5>;
+            auto ka = abl == 1 ? attn_fwd32d_kernel<72, 1> : abl == 4 ? attn_fwd32d_kernel<72, 4> : abl == 8 ? attn_fwd32d_kernel<72, 8>
+                      : abl == 16 ? attn_fwd32d_kernel<72, 16> : abl == 24 ? attn_fwd32d_kernel<72, 24> : attn_fwd32d_kernel<72, 5>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             hipLaunchKernelGGL(ka, dim3(8 * ((G + 7) / 8) * nqt), dim3(512), LDS, st, a);
             return vq_check_launch();
