@@ -378,3 +378,26 @@ def test_graphed_model_falls_through_without_a_gpu_and_keys_on_argument_identity
     layer.smooth_quant_running_stat, layer.channel_wise_scale_type = True, "momentum_act_max"
     assert gm._state(None)[2]                                      # host-visible running statistic: not capturable
     assert GraphedModel(lambda *a, **k: None, qnn=torch.nn.Sequential(torch.nn.Linear(2, 2)))._state(None) == (hash(()), 0, False)
+
+
+def test_fp_edge_and_gelu_one_pass_routing_decisions():
+    """Host-side routing added in round 4: the FP-edge HIP kernel is only chosen for fp16 GPU tensors of layers in FP state
+    (on CPU the module path runs - this container has no GPU), and the one-pass GELU quantizer covers B = 1, and B = 2
+    without smoothing or with long rows."""
+    import viditq_amd  # noqa: F401
+    from viditq_amd.t2v.stdit import Mlp, TimestepEmbedder, fp_edge_linear
+    lin = torch.nn.Linear(16, 8)
+    x = torch.randn(3, 16)
+    assert fp_edge_linear(lin, x) is None                          # CPU tensor: the caller takes the module path
+    assert fp_edge_linear(lin, x.half()) is None
+    m = Mlp(16, 32, 8)
+    assert torch.allclose(m(x), m.fc2(m.act(m.fc1(x))))            # ... which is what the modules then compute
+    te = TimestepEmbedder(8, frequency_embedding_size=16)
+    t = torch.tensor([3.0, 700.0])
+    assert torch.allclose(te(t, torch.float32), te.mlp(te.timestep_embedding(t, 16)))
+    qnn = _tiny_qnn()
+    fc2 = dict(qnn.quant_layers())["blocks.0.mlp.fc2"]
+    s = torch.ones(fc2.in_features)
+    assert fc2.gelu_one_pass_ok(1, fc2.in_features, None) and fc2.gelu_one_pass_ok(1, fc2.in_features, s)
+    assert fc2.gelu_one_pass_ok(2, fc2.in_features, None) and fc2.gelu_one_pass_ok(2, 4608, s)
+    assert not fc2.gelu_one_pass_ok(2, 1152, s) and not fc2.gelu_one_pass_ok(3, 4608, None)
