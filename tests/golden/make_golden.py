@@ -906,6 +906,42 @@ def xl_depth6(R):
     npz("xl_depth6_ref.npz", **out)
 
 
+def xl_depth6_pixart():
+    """The PixArt counterpart of :func:`xl_depth6` (BASELINE config 5's plan at full width): six PixArt-MS blocks at C = 1152 /
+    16 heads / mlp 4608, 64 image tokens, B = 2 (uncond | cond with shared token grids), W4A8 (4-bit weights, dynamic A8, no
+    channel balancing), the t2i FP list (final layer QUANTIZED), seeded weights - blocks 1, 3, 5 and the model output in the
+    reference's fp32 mode and in its fp16 mode."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict
+    import copy
+    seed = XL_SEED + 200
+    out = {"seed": np.array(seed)}
+    Rt = ref_import.load_t2i()
+    mp = Rt.PixArtMS(input_size=16, depth=6, hidden_size=1152, num_heads=16, model_max_length=12, caption_channels=64)
+    mp.load_state_dict(seeded_state_dict(mp, seed), strict=True)
+    mp.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    x = h(torch.randn(2, 4, 16, 16, generator=g))
+    y = h(torch.randn(2, 1, 12, 64, generator=g) * 0.5)
+    mask = torch.zeros(2, 12, dtype=torch.int64)
+    mask[0, :11] = 1
+    mask[1, :6] = 1
+    t = torch.tensor([611, 611])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    with torch.no_grad():
+        qnn = _pixart_ptq(Rt, copy.deepcopy(mp), ref_import.wq_cfg(4, mixed_precision=[4, 6, 8]),
+                          ref_import.aq_cfg(T=1, S=64, n_prompt=12), x, t, y, mask)
+        for tag, q, yy in (("", qnn, y), ("_ref_fp16", _half_copy(qnn), y.half())):
+            blocks = []
+            hooks = [b.register_forward_hook(lambda mod, i, o: blocks.append(o.clone())) for b in q.model.blocks]
+            out["w4a8_out" + tag] = q(x, t, yy, mask=mask).float()
+            for hk in hooks:
+                hk.remove()
+            for i in (1, 3, 5):
+                out["w4a8_block%d%s" % (i, tag)] = blocks[i].float()
+    npz("xl_depth6_pixart_ref.npz", **out)
+
+
 def tiny_vae_wrapper():
     """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
     a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
@@ -1008,6 +1044,8 @@ def main():
             tiny_pixart_alpha()
         if want("pixart_w4a8"):
             tiny_pixart_w4a8()
+        if want("xl_depth6_pixart"):
+            xl_depth6_pixart()
 
 
 if __name__ == "__main__":

@@ -422,6 +422,27 @@ def test_xl_depth6_reference_vectors_pin_the_oracle_over_depth_at_c1152():
     assert rel_l2(out, g["w8a8_out"]) < 0.45 * rel_l2(g["w8a8_out_ref_fp16"], g["w8a8_out"])
 
 
+def test_xl_depth6_pixart_reference_vectors_pin_the_oracle_over_depth_at_c1152():
+    """The PixArt counterpart (make_golden.py::xl_depth6_pixart): six PixArt-MS blocks at C = 1152, B = 2, W4A8 with the
+    t2i FP list (quantized final layer), from the IMPORTED REFERENCE on seeded weights - blocks 1, 3, 5 and the output.
+    Same law as the STDiT case, with twice the rows per quantizer call (B = 2) and a quantized final layer: code flips at
+    rounding ties appear from block 1 on (2.0e-4 / 5.5e-4 / 8.2e-4 at blocks 1 / 3 / 5, output 4.7e-3) and stay below
+    0.45 x the reference's own fp16-mode drift (2.3e-3 / 3.3e-3 / 4.0e-3, output 1.9e-2)."""
+    from oracle import pixart_ref as pr
+    g = load_npz("xl_depth6_pixart_ref.npz")
+    sd = _seeded_sd("pixart", int(g["seed"]), depth=6)
+    pe = load_npz("xl_width_ref.npz")["pixart_pos_embed"]       # same geometry (16 x 16 latent, patch 2)
+    out, blocks = pr.pixart_forward(sd, dict(H=16, depth=6, patch=2, out_ch=8), g["x"], g["t"], g["y"], g["mask"],
+                                    sr.QSpec(w_bits=4, fp_layers=pr.T2I_FP_LAYERS), pe, return_blocks=True)
+    errs = {}
+    for i in (1, 3, 5):
+        ref16 = rel_l2(g["w4a8_block%d_ref_fp16" % i], g["w4a8_block%d" % i])
+        errs[i] = (rel_l2(blocks[i], g["w4a8_block%d" % i]), ref16)
+        assert errs[i][0] < 0.45 * ref16, errs
+    ref16 = rel_l2(g["w4a8_out_ref_fp16"], g["w4a8_out"])
+    assert rel_l2(out, g["w4a8_out"]) < 0.45 * ref16, (rel_l2(out, g["w4a8_out"]), ref16, errs)
+
+
 ATTN_KAT_CASES = [("L1024", 2, 1024, 16), ("L160", 3, 160, 4), ("L16", 64, 16, 8)]   # as tests/golden/make_golden.py
 
 
