@@ -428,15 +428,22 @@ def main():
     extras = None
     if rank == 0 and world == 1 and a.plan == "w8a8" and not a.no_extras and a.depth == 28 and not a.prompts:
         extras = {}
-        legs = stdit_legs(a, dev, 0, 1, ["w4a8", "w4a8_mp"], 4, 2, events=not a.no_roofline_events, hoisted=False)
-        for plan, r in zip(("w4a8", "w4a8_mp"), legs):
-            extras[plan] = {"value": r["steps"] / r["el"], "unit": "denoising steps/s", "steps": r["steps"], "warmup": 2,
-                            "ms_per_step": r["el"] / r["steps"] * 1e3, "schedule": "DDIM-%d" % r["n_sampling"],
-                            "status_word": r["status"],
-                            "gemm_frac_of_int8_peak": r["roofline"]["frac"] if r["roofline"] else None,
-                            "gemm_avg_launch_us": r["roofline"]["avg_launch_us"] if r["roofline"] else None,
-                            "gemm_time_share_of_step": r["roofline"]["gemm_time_share_of_step"] if r["roofline"] else None}
-        extras["pixart_sigma_1024_w4a8"] = pixart_leg(dev)
+        # a leg that fails reports its error; the headline line above is already measured and is printed regardless
+        try:
+            legs = stdit_legs(a, dev, 0, 1, ["w4a8", "w4a8_mp"], 4, 2, events=not a.no_roofline_events, hoisted=False)
+            for plan, r in zip(("w4a8", "w4a8_mp"), legs):
+                extras[plan] = {"value": r["steps"] / r["el"], "unit": "denoising steps/s", "steps": r["steps"], "warmup": 2,
+                                "ms_per_step": r["el"] / r["steps"] * 1e3, "schedule": "DDIM-%d" % r["n_sampling"],
+                                "status_word": r["status"],
+                                "gemm_frac_of_int8_peak": r["roofline"]["frac"] if r["roofline"] else None,
+                                "gemm_avg_launch_us": r["roofline"]["avg_launch_us"] if r["roofline"] else None,
+                                "gemm_time_share_of_step": r["roofline"]["gemm_time_share_of_step"] if r["roofline"] else None}
+        except Exception as e:  # noqa: BLE001
+            extras["w4a8"] = extras["w4a8_mp"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            extras["pixart_sigma_1024_w4a8"] = pixart_leg(dev)
+        except Exception as e:  # noqa: BLE001
+            extras["pixart_sigma_1024_w4a8"] = {"error": "%s: %s" % (type(e).__name__, e)}
         extras["note"] = ("other single-GPU configurations of BASELINE.json on the same build; synthetic calibration "
                           "(viditq_amd.synth); NOT the headline value")
 
@@ -474,7 +481,11 @@ def main():
         if rehearsal:
             line["rehearsal"] = "ranks share devices, gloo backend: control-flow dry run, NOT a measurement"
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001  (a reported side measurement: its failure must not lose the GPU line)
+                line["cpu_baseline"] = {"value": None, "unit": "denoising steps/s", "cores": 0, "kind": "port",
+                                        "sample": "failed: %s: %s" % (type(e).__name__, e)}
         check_line(line, a)
         print(json.dumps(line), flush=True)
     if dist is not None:
