@@ -76,6 +76,88 @@ def test_argument_validation_without_gpu():
     assert lib.vq_attn_temporal(one, one, one, one, 1, 17, 4, 4, 72, 8, 8, 1.0, None) == -2
 
 
+def _args(name, ptr, ints=None, longs=None):
+    """Arguments for `name` from its binding: every pointer = `ptr`, every int 1 / long 8 / float 1.0 unless a position is
+    given in `ints` / `longs` (position = index in the parameter list)."""
+    import ctypes as C
+    from viditq_amd import _lib
+    out = []
+    for i, ct in enumerate(_lib.SIGNATURES[name][1]):
+        if ct is C.c_void_p:
+            out.append(ptr)
+        elif ct is C.c_float:
+            out.append(1.0)
+        elif ct is C.c_long:
+            out.append((longs or {}).get(i, 8))
+        else:
+            out.append((ints or {}).get(i, 1))
+    return out
+
+
+def test_every_entry_point_rejects_null_and_bad_shapes_without_gpu():
+    """Error behaviour of the whole ABI (include/viditq.h: 0 ok / negative code, never throws, nothing dereferenced or
+    launched before the checks): for EVERY compute entry point, null pointers -> VQ_EINVAL, a non-positive size ->
+    VQ_EINVAL, and - with non-null dummies that the checks must not dereference - one shape / alignment violation ->
+    VQ_ESHAPE and one unsupported width / mode -> VQ_EUNSUP.  Positions are parameter indices of the header."""
+    import viditq_amd  # noqa: F401
+    from viditq_amd import _lib
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)
+    compute = [n for n in _lib.SIGNATURES if n not in ("vq_version", "vq_strerror", "vq_last_hip_error")]
+    assert len(compute) >= 19
+    for name in compute:
+        fn = getattr(lib, name)
+        assert fn(*_args(name, None)) == -1, name                       # null pointers
+    # a zero extent with non-null pointers (position of one size parameter per entry point)
+    zero_size = {"vq_rowquant": 15, "vq_gelu_rowquant": 8, "vq_ln_modulate_rowquant": 13, "vq_rowquant_smooth_multi": 8,
+                 "vq_smooth_reciprocal": 2, "vq_fakequant_act": 9, "vq_epsfill_fixup": 7, "vq_pack_weight": 8,
+                 "vq_weight_minmax": 4, "vq_gemm_i8": 14, "vq_gemm_i8_batched": 11, "vq_gemm_i8_grouped": 12,
+                 "vq_attn_fwd": 5, "vq_attn_temporal": 6, "vq_attn_temporal_rowquant": 13, "vq_adaln_table": 4,
+                 "vq_linear_f16": 4, "vq_cfg_ddim_step": 4}
+    for name, pos in zero_size.items():
+        assert getattr(lib, name)(*_args(name, one, ints={pos: 0})) == -1, name
+    assert lib.vq_smooth_div_check(one, one, one, one, 0, None) == -1
+    # shape / alignment: {position: value} on top of a consistent base (C = 64, Kp = 128, widths 8)
+    shape = {
+        "vq_rowquant": ({14: 1, 15: 4, 16: 60, 17: 128, 18: 8}, -2),                 # C % 8
+        "vq_gelu_rowquant": ({7: 1, 8: 4, 9: 64, 10: 100, 11: 8}, -2),               # Kp % 128
+        "vq_ln_modulate_rowquant": ({4: 1, 12: 1, 13: 4, 14: 64, 15: 0, 16: 8}, -2),  # Kp < C
+        "vq_rowquant_smooth_multi": ({1: 1, 8: 4, 9: 62, 10: 128, 11: 8}, -2),
+        "vq_fakequant_act": ({7: 1, 8: 1, 9: 4, 10: 60, 11: 8, 12: 0}, -2),
+        "vq_epsfill_fixup": ({6: 1, 7: 70000, 8: 64, 9: 64, 10: 8}, -2),             # L > 65535
+        "vq_pack_weight": ({8: 4, 9: 64, 10: 64, 11: 8}, -2),                        # Kp % 128
+        "vq_gemm_i8": ({10: 64, 13: 1, 14: 4, 15: 62, 16: 64, 17: 128, 18: 8, 19: 0, 20: 0}, -2),       # N % 4
+        "vq_gemm_i8_batched": ({10: 1, 11: 4, 12: 64, 13: 64, 14: 120, 15: 8}, -2),
+        "vq_gemm_i8_grouped": ({0: 2, 11: 64, 12: 4, 13: 64, 14: 64, 15: 128, 16: 8}, -2),             # ldo < 2 N
+        "vq_attn_temporal": ({4: 1, 5: 17, 6: 4, 7: 4, 8: 72}, -2),                  # T > 16
+        "vq_attn_temporal_rowquant": ({11: 1, 12: 16, 13: 4, 14: 4, 15: 72, 17: 100}, -2),
+        "vq_linear_f16": ({4: 4, 5: 64, 6: 60, 10: 0, 11: 0}, -2),                   # K % 8
+    }
+    for name, (ints, code) in shape.items():
+        longs = {i: 128 for i, ct in enumerate(_lib.SIGNATURES[name][1]) if ct is ctypes.c_long}
+        assert getattr(lib, name)(*_args(name, one, ints=ints, longs=longs)) == code, name
+    assert lib.vq_attn_fwd(*_args("vq_attn_fwd", one, ints={4: 1, 5: 4, 6: 4, 7: 1, 8: 72}, longs={10: 12})) == -2   # row % 8
+    unsup = {
+        "vq_rowquant": {14: 1, 15: 4, 16: 64, 17: 128, 18: 9},
+        "vq_gelu_rowquant": {7: 3, 8: 4, 9: 64, 10: 128, 11: 8},                    # B > 2: GEMM epilogue route
+        "vq_ln_modulate_rowquant": {4: 1, 12: 1, 13: 4, 14: 64, 15: 128, 16: 1},
+        "vq_rowquant_smooth_multi": {1: 1, 8: 4, 9: 64, 10: 128, 11: 12},
+        "vq_fakequant_act": {7: 1, 8: 1, 9: 4, 10: 64, 11: 1, 12: 0},
+        "vq_epsfill_fixup": {6: 1, 7: 4, 8: 64, 9: 64, 10: 9},
+        "vq_pack_weight": {8: 4, 9: 64, 10: 128, 11: 16},
+        "vq_weight_minmax": {4: 4, 5: 64, 6: 1, 7: 0},
+        "vq_gemm_i8": {10: 64, 13: 1, 14: 4, 15: 64, 16: 64, 17: 128, 18: 8, 19: 7, 20: 0},           # epilogue kind
+        "vq_gemm_i8_batched": {10: 1, 11: 4, 12: 64, 13: 64, 14: 128, 15: 4},        # batched form: 8-bit images only
+        "vq_gemm_i8_grouped": {0: 2, 11: 128, 12: 4, 13: 64, 14: 64, 15: 128, 16: 9},
+        "vq_linear_f16": {4: 4, 5: 64, 6: 64, 10: 2, 11: 2},                         # act pair the models never use
+    }
+    for name, ints in unsup.items():
+        longs = {i: 128 for i, ct in enumerate(_lib.SIGNATURES[name][1]) if ct is ctypes.c_long}
+        assert getattr(lib, name)(*_args(name, one, ints=ints, longs=longs)) == -4, name
+    for code in (0, -1, -2, -3, -4, -99):
+        assert lib.vq_strerror(code)
+
+
 def test_product_ops_refuse_cpu_tensors():
     import pytest
     import torch
