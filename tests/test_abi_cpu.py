@@ -159,9 +159,39 @@ def test_every_entry_point_rejects_null_and_bad_shapes_without_gpu():
 
 
 def test_product_ops_refuse_cpu_tensors():
+    """No CPU / eager fallback anywhere in the operator layer: every wrapper of viditq_amd.ops raises VQError on a CPU
+    tensor instead of computing something else."""
     import pytest
     import torch
     import viditq_amd  # noqa: F401
     from viditq_amd import ops
-    with pytest.raises(ops.VQError):
-        ops.rowquant(torch.zeros(1, 4, 64, dtype=torch.float16))
+
+    def h(*s):
+        return torch.zeros(*s, dtype=torch.float16)
+
+    def f(*s):
+        return torch.ones(*s, dtype=torch.float32)
+    cases = {
+        "rowquant": lambda: ops.rowquant(h(1, 4, 64)),
+        "rowquant_multi": lambda: ops.rowquant_multi(h(1, 4, 64), [f(64)]),
+        "gelu_rowquant": lambda: ops.gelu_rowquant(h(1, 4, 64)),
+        "ln_modulate_rowquant": lambda: ops.ln_modulate_rowquant(h(1, 4, 64), f(1, 64), f(1, 64)),
+        "fakequant_act": lambda: ops.fakequant_act(h(1, 4, 64)),
+        "weight_minmax": lambda: ops.weight_minmax(h(8, 64), 8),
+        "pack_weight": lambda: ops.pack_weight(h(8, 64), f(8, 1), f(8, 1), 8),
+        "attn_fwd": lambda: ops.attn_fwd(h(1, 4, 72), h(1, 4, 72), h(1, 4, 72), h(1, 4, 72), 1, 4, 4, 1, 72, 288, 72, 288, 72,
+                                         288, 72),
+        "attn_temporal": lambda: ops.attn_temporal(h(4, 72), h(4, 72), h(4, 72), h(4, 72), 1, 4, 1, 1, 72, 72, 72),
+        "attn_temporal_rowquant": lambda: ops.attn_temporal_rowquant(h(64, 64), h(64, 64), h(64, 64), 1, 16, 4, 4, 16, 64),
+        "adaln_table": lambda: ops.adaln_table(h(6, 64), h(1, 384)),
+        "linear_f16": lambda: ops.linear_f16(h(4, 64), h(8, 64)),
+        "cfg_ddim_step": lambda: ops.cfg_ddim_step(f(1, 8, 4), f(1, 8, 4), f(1, 4, 4), 4.0, 1.0, 1.0, 1.0, 0.5),
+        "smooth_rcp": lambda: ops.smooth_rcp(f(64)),
+        "smooth_div_check": lambda: ops.smooth_div_check(f(64), f(64)),
+        "epsfill_fixup": lambda: ops.epsfill_fixup(torch.zeros(1, dtype=torch.int32), h(1, 4, 64), None, h(8, 64), None,
+                                                   h(1, 4, 8), 8),
+    }
+    for name, call in cases.items():
+        with pytest.raises(ops.VQError):
+            call()
+        assert name in dir(ops)

@@ -99,9 +99,9 @@ def smooth_rcp(s: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     ent = _RCP_CACHE.get(key)
     if ent is not None and ent[0]() is s and ent[1] == s._version:
         return ent[2]
+    _req(s, torch.float32, "s")
     if torch.cuda.is_current_stream_capturing():
         return None                       # an unseen vector under capture: exact division, no host round trip
-    _req(s, torch.float32, "s")
     r = torch.empty_like(s)
     bad = torch.zeros(1, dtype=torch.int32, device=s.device)
     check(_L().vq_smooth_reciprocal(_p(s), _p(r), s.numel(), _p(bad), _stream()), "vq_smooth_reciprocal")
