@@ -942,6 +942,61 @@ def xl_depth6_pixart():
     npz("xl_depth6_pixart_ref.npz", **out)
 
 
+ALPHA_SEED = 4301
+
+
+def alpha256_full():
+    """BASELINE config 1 at FULL SIZE, end to end, from the imported reference: PixArt-alpha XL/2 at 256 x 256 (32 x 32 latent,
+    N = 256 tokens, depth 28, C = 1152, 16 heads, 120 prompt tokens of 4096), W8A8 per-token dynamic with the t2i FP list,
+    ONE prompt, DPM-Solver++ 2M with 20 steps and cfg 4.5 through the alpha entry point (quant_txt2img.py:130-153) -
+    seeded weights (not stored), the latent after 1, 5, 10 and 20 solver steps, in the reference's fp32 mode and its fp16
+    mode."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict
+    import copy
+    import importlib
+    import time
+    Rt = ref_import.load_t2i()
+    PixArt = importlib.import_module("diffusion.model.nets.PixArt").PixArt
+    dps = importlib.import_module("diffusion.dpm_solver_alpha")
+    out = {"seed": np.array(ALPHA_SEED)}
+    m = PixArt(input_size=32, depth=28, hidden_size=1152, num_heads=16, model_max_length=120, caption_channels=4096)
+    m.load_state_dict(seeded_state_dict(m, ALPHA_SEED), strict=True)
+    m.eval()
+    from helpers import alpha256_inputs
+    z, y, null_y, mask = alpha256_inputs(ALPHA_SEED)
+    t = torch.tensor([500])
+    out["pos_embed"] = m.pos_embed.detach().numpy().astype(np.float16)     # fp16-representable (seeded_state_dict): lossless
+    with torch.no_grad():
+        qnn = _pixart_ptq(Rt, copy.deepcopy(m), ref_import.wq_cfg(8), ref_import.aq_cfg(T=1, S=256, n_prompt=120),
+                          z, t, y, mask)
+        assert type(qnn.model.blocks[0]).__name__ == "PixArtBlock"
+        for tag, q, cast in (("", qnn, lambda v: v), ("_ref_fp16", _half_copy(qnn), lambda v: v.half())):
+            t0 = time.time()
+            seen = []
+
+            def fwd(x_, t_, y_, _q=q, _tag=tag, **kw):   # the k-th model call sees the latent after k solver steps
+                seen.append(x_.detach().float().clone())
+                if len(seen) == 1:                  # first call: block 0 (every 8th token) and the raw model output
+                    hk = _q.model.blocks[0].register_forward_hook(
+                        lambda mod, i, o: out.__setitem__("call0_block0" + _tag, o.detach().float()[:, ::8].clone()))
+                    r = _q.forward_with_dpmsolver(x_, t_, y_, **kw)
+                    hk.remove()
+                    out["call0_eps" + _tag] = r.detach().float().clone()
+                    out["call0_t"] = t_.detach().float().clone()
+                    return r
+                return _q.forward_with_dpmsolver(x_, t_, y_, **kw)
+            solver = dps.DPMS_alpha(fwd, condition=cast(y), uncondition=cast(null_y), cfg_scale=4.5,
+                                    model_kwargs=dict(data_info=None, mask=mask))
+            final = solver.sample(z, steps=20, order=2, skip_type="time_uniform", method="multistep")
+            assert len(seen) == 20, len(seen)
+            out["final" + tag] = final.float()
+            for k in (1, 5, 10):
+                out["x%d%s" % (k, tag)] = seen[k][:1]
+            print("alpha256", tag or "fp32", "%.1f s" % (time.time() - t0), flush=True)
+    npz("alpha256_full_ref.npz", **out)
+
+
 def tiny_vae_wrapper():
     """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
     a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
@@ -1046,6 +1101,8 @@ def main():
             tiny_pixart_w4a8()
         if want("xl_depth6_pixart"):
             xl_depth6_pixart()
+        if want("alpha256_full"):
+            alpha256_full()
 
 
 if __name__ == "__main__":

@@ -151,3 +151,15 @@ def attn_kat_input(seed: int, name: str, nseq: int, L: int, C: int = 1152):
     import zlib
     g = torch.Generator().manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
     return torch.randn(nseq, L, C, generator=g).half().float()
+
+
+def alpha256_inputs(seed: int):
+    """Inputs of the full-size PixArt-alpha 256^2 trajectory (tests/golden/alpha256_full_ref.npz) from the seed alone:
+    latent z [1, 4, 32, 32], prompt / null embeddings [1, 1, 120, 4096] (fp16-representable values), a 77-token prompt."""
+    g = torch.Generator().manual_seed(int(seed) + 1)
+    z = torch.randn(1, 4, 32, 32, generator=g).half().float()
+    y = (torch.randn(1, 1, 120, 4096, generator=g) * 0.5).half().float()
+    null_y = (torch.randn(1, 1, 120, 4096, generator=g) * 0.5).half().float()
+    mask = torch.zeros(1, 120, dtype=torch.int64)
+    mask[0, :77] = 1
+    return z, y, null_y, mask
