@@ -997,6 +997,55 @@ def alpha256_full():
     npz("alpha256_full_ref.npz", **out)
 
 
+STDIT_FULL_SEED = 5501
+
+
+def stdit_full(R):
+    """BASELINE's HEADLINE configuration at FULL SIZE on the reference itself: STDiT-XL/2 16 x 512 x 512 - latent
+    [1, 4, 16, 64, 64], 16384 tokens, depth 28, C = 1152, 120 x 4096 prompt (80 tokens kept), W8A8 per-token dynamic,
+    cfg_split (one B = 1 forward-sample), seeded weights (NOT stored) - one conditional forward in the reference's fp32 mode
+    and in its fp16 mode (~2 minutes each on 8 cores).  Stored: every 256th token row of blocks 0 / 13 / 27 and the model
+    output at every second spatial position; fp16-mode arrays as float16 (their values are fp16)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict, stdit_full_inputs
+    import time
+    seed = STDIT_FULL_SEED
+    out = {"seed": np.array(seed)}
+    m = R.STDiT(enable_flashattn=False, input_size=(16, 64, 64), depth=28, hidden_size=1152, num_heads=16, model_max_length=120,
+                caption_channels=4096)
+    m.load_state_dict(seeded_state_dict(m, seed), strict=True)
+    m.eval()
+    x, y, mask, t = stdit_full_inputs(seed)
+    with torch.no_grad():
+        wq = ref_import.wq_cfg(8, mixed_precision=[4, 6, 8])
+        aq = ref_import.aq_cfg(T=16, S=1024, n_prompt=120)
+        qnn = R.QuantModel(m, wq, aq)
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.fp_layer_list = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+        qnn.set_quant_state(True, False)
+        t0 = time.time()
+        qnn(x, t, y, mask=mask)
+        print("stdit_full weight-init forward %.0f s" % (time.time() - t0), flush=True)
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_init_done("activation")
+        qnn.set_quant_state(True, True)
+        qnn.cfg_split = True
+        for tag, q, yy in (("", qnn, y), ("_ref_fp16", _half_copy(qnn), y.half())):
+            t0 = time.time()
+            blocks = {}
+            hooks = [q.model.blocks[i].register_forward_hook(
+                lambda mod, inp, o, i=i: blocks.__setitem__(i, o.detach().float()[:, ::256].clone())) for i in (0, 13, 27)]
+            o = q(x, t, yy, mask=mask).float()
+            for hk in hooks:
+                hk.remove()
+            cast = (lambda v: v.numpy().astype(np.float16)) if tag else (lambda v: v)
+            out["out" + tag] = cast(o[:, :, :, ::2, ::2].contiguous())
+            for i, b in blocks.items():
+                out["block%d%s" % (i, tag)] = cast(b)
+            print("stdit_full", tag or "fp32", "%.0f s" % (time.time() - t0), flush=True)
+    npz("stdit_full_ref.npz", **out)
+
+
 def tiny_vae_wrapper():
     """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
     a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
@@ -1088,6 +1137,8 @@ def main():
             xl_width(R)
         if want("xl_depth6"):
             xl_depth6(R)
+        if "stdit_full" in only:            # ~8 minutes of CPU: only when asked for by name
+            stdit_full(R)
         if want("vae"):
             tiny_vae_wrapper()
         if want("attn_kats"):

@@ -108,8 +108,8 @@ class spy_fused:
         self.orig = self.cls.forward_fused
         rec, orig = self.blocks, self.orig
 
-        def spy(mod, x2, *a, **k):
-            r = orig(mod, x2, *a, **k)
+        def spy(block_, x2, *a, **k):          # (the fused route passes a keyword named ``mod``)
+            r = orig(block_, x2, *a, **k)
             rec.append(x2.clone())
             return r
         self.cls.forward_fused = spy
@@ -163,3 +163,14 @@ def alpha256_inputs(seed: int):
     mask = torch.zeros(1, 120, dtype=torch.int64)
     mask[0, :77] = 1
     return z, y, null_y, mask
+
+
+def stdit_full_inputs(seed: int):
+    """Inputs of the full-size STDiT forward (tests/golden/stdit_full_ref.npz) from the seed alone: latent [1, 4, 16, 64, 64],
+    prompt embedding [1, 1, 120, 4096] (fp16-representable values), 80 prompt tokens kept, timestep 577."""
+    g = torch.Generator().manual_seed(int(seed) + 1)
+    x = torch.randn(1, 4, 16, 64, 64, generator=g).half().float()
+    y = (torch.randn(1, 1, 120, 4096, generator=g) * 0.5).half().float()
+    mask = torch.zeros(1, 120, dtype=torch.int64)
+    mask[0, :80] = 1
+    return x, y, mask, torch.tensor([577])

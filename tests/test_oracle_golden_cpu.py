@@ -499,6 +499,28 @@ def test_alpha256_full_size_trajectory_pins_the_oracle_on_the_reference():
     assert errs[5][0] < 1.0 * errs[5][1], errs
 
 
+def test_stdit_full_size_block0_pins_the_oracle_on_the_reference():
+    """BASELINE's headline configuration at FULL SIZE on the reference itself (make_golden.py::stdit_full: STDiT-XL/2, latent
+    [1, 4, 16, 64, 64] = 16384 tokens, 120 x 4096 prompt with 80 tokens kept, W8A8 dynamic, seeded weights): the oracle's
+    embedders + block 0 over all 16384 tokens against every 256th token row of the reference's block 0 (the deeper blocks and
+    the output of the same forward are the GPU test's vectors; the full-depth oracle forward is too slow for this suite).
+    The position tables come from the product's host code (rounded to fp16 like the reference's buffers): an error there
+    would show here, block 0 carries them in its residual."""
+    from helpers import stdit_full_inputs
+    from viditq_amd.t2v import STDiT
+    g = load_npz("stdit_full_ref.npz")
+    seed = int(g["seed"])
+    sd = _seeded_sd("stdit", seed, depth=1, Cc=4096, L=120)
+    geo = STDiT(input_size=(16, 64, 64), depth=1, hidden_size=1152, num_heads=16, model_max_length=120, caption_channels=4096)
+    sd["pos_embed"], sd["pos_embed_temporal"] = geo.pos_embed.half().float(), geo.pos_embed_temporal.half().float()
+    x, y, mask, t = stdit_full_inputs(seed)
+    cfg = dict(T=16, S=1024, H=16, depth=1, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(16, 64, 64))
+    _, blocks = sr.stdit_forward(sd, cfg, x, t, y, mask, sr.QSpec(w_bits=8), return_blocks=True)
+    e = rel_l2(blocks[0][:, ::256], g["block0"])
+    ref16 = rel_l2(g["block0_ref_fp16"], g["block0"])
+    assert e < 2e-5 and e < 0.05 * ref16, (e, ref16)
+
+
 ATTN_KAT_CASES = [("L1024", 2, 1024, 16), ("L160", 3, 160, 4), ("L16", 64, 16, 8)]   # as tests/golden/make_golden.py
 
 
