@@ -1046,6 +1046,108 @@ def stdit_full(R):
     npz("stdit_full_ref.npz", **out)
 
 
+def stdit_full_w4a8(R):
+    """BASELINE config 3 at FULL SIZE on the reference itself: the model and inputs of :func:`stdit_full` under the ViDiT-Q
+    W4A8 plan - 4-bit per-channel weights (grids for [4, 6, 8]), per-token dynamic A8, channel balancing alpha = 0.11 over
+    the time ranges [0, 500] / [501, 1000] with a seeded activation statistic (tests/helpers.py::seeded_act_scale, injected
+    where calibration would leave it), weight grids initialised by one weight-quantized forward per range (ptq.py:266-293) -
+    (a) at t = 721 (range 1); (b) at t = 300 (range 0) with per-layer bit widths (mlp 8-bit, attention 4-bit: the released
+    mixed-precision allocation) set through load_bitwidth_config.  fp32 mode and fp16 mode; stored: every 512th token row of
+    block 27 and the model output at every second frame / spatial position."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict, seeded_act_scale, stdit_full_inputs
+    import time
+    seed = STDIT_FULL_SEED
+    out = {"seed": np.array(seed)}
+    m = R.STDiT(enable_flashattn=False, input_size=(16, 64, 64), depth=28, hidden_size=1152, num_heads=16, model_max_length=120,
+                caption_channels=4096)
+    m.load_state_dict(seeded_state_dict(m, seed), strict=True)
+    m.eval()
+    x, y, mask, _ = stdit_full_inputs(seed)
+    fp = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+    smooth = dict(alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]])
+    with torch.no_grad():
+        wq = ref_import.wq_cfg(4, mixed_precision=[4, 6, 8])
+        aq = ref_import.aq_cfg(T=16, S=1024, n_prompt=120, smooth=smooth)
+        qnn = R.QuantModel(m, wq, aq)
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.fp_layer_list = list(fp)
+        qnn.cfg_split = True
+        n_inj = 0
+        for name, mod in qnn.model.named_modules():
+            if isinstance(mod, R.QuantLayer) and not any(name.startswith(f) for f in fp):
+                mod.act_quantizer.act_scale = seeded_act_scale(name, mod.weight.shape[1], seed)
+                n_inj += 1
+        assert n_inj == 13 * 28, n_inj
+        qnn.set_smooth_quant(smooth_quant=True, smooth_quant_running_stat=False)
+        qnn.set_layer_smooth_quant(model=qnn, module_name_list=fp, smooth_quant=False, smooth_quant_running_stat=False)
+        qnn.set_quant_state(True, False)
+        t0 = time.time()
+        for tt in (torch.tensor([0]), torch.tensor([501])):
+            qnn(x, tt, y, mask=mask)
+        print("stdit_full_w4a8 weight-init forwards %.0f s" % (time.time() - t0), flush=True)
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_init_done("activation")
+        qnn.set_quant_state(True, True)
+        names = [n for n, mod in qnn.named_modules() if isinstance(mod, R.QuantLayer) and ".blocks." in n]
+        for case, tv, mp in (("w4a8_t721", 721, None), ("w4a8_mp_t300", 300, {n: (8 if ".mlp." in n else 4) for n in names})):
+            if mp is not None:
+                qnn.load_bitwidth_config(qnn, mp, "weight")
+            for tag, q, yy in (("", qnn, y), ("_ref_fp16", _half_copy(qnn), y.half())):
+                t0 = time.time()
+                blocks = {}
+                hk = q.model.blocks[27].register_forward_hook(
+                    lambda mod, inp, o: blocks.__setitem__(27, o.detach().float()[:, ::512].clone()))
+                o = q(x, torch.tensor([tv]), yy, mask=mask).float()
+                hk.remove()
+                out["%s_out%s" % (case, tag)] = o[:, :, ::2, ::2, ::2].contiguous()
+                out["%s_block27%s" % (case, tag)] = blocks[27]
+                print("stdit_full_w4a8", case, tag or "fp32", "%.0f s" % (time.time() - t0), flush=True)
+                del q
+    npz("stdit_full_w4a8_ref.npz", **out)
+
+
+SIGMA_SEED = 6601
+
+
+def sigma1024_full():
+    """BASELINE config 5 at FULL SIZE on the reference itself: PixArt-Sigma XL/2 (PixArtMS, pe_interpolation 2) at 1024 x 1024 -
+    latents [2, 4, 128, 128] (uncond | cond in one batch: token grids shared over the pair), 4096 image tokens, depth 28,
+    prompts of 300 / 143 tokens of 4096 channels, 4-bit weights (grids for [4, 6, 8]), per-token dynamic A8, the t2i FP list
+    (final layer quantized), seeded weights - one forward in the reference's fp32 mode and in its fp16 mode.  Stored: every
+    128th token row of blocks 0 and 27 and the output at every second spatial position."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict, sigma1024_inputs
+    import copy
+    import time
+    seed = SIGMA_SEED
+    out = {"seed": np.array(seed)}
+    Rt = ref_import.load_t2i()
+    mp = Rt.PixArtMS(input_size=128, depth=28, hidden_size=1152, num_heads=16, model_max_length=300, caption_channels=4096,
+                     pe_interpolation=2.0)
+    mp.load_state_dict(seeded_state_dict(mp, seed), strict=True)
+    mp.eval()
+    x, y, mask, t = sigma1024_inputs(seed)
+    with torch.no_grad():
+        t0 = time.time()
+        qnn = _pixart_ptq(Rt, mp, ref_import.wq_cfg(4, mixed_precision=[4, 6, 8]), ref_import.aq_cfg(T=1, S=4096, n_prompt=300),
+                          x, t, y, mask)
+        print("sigma1024 ptq forwards %.0f s" % (time.time() - t0), flush=True)
+        for tag, q, yy in (("", qnn, y), ("_ref_fp16", _half_copy(qnn), y.half())):
+            t0 = time.time()
+            blocks = {}
+            hooks = [q.model.blocks[i].register_forward_hook(
+                lambda mod, inp, o, i=i: blocks.__setitem__(i, o.detach().float()[:, ::128].clone())) for i in (0, 27)]
+            o = q(x, t, yy, mask=mask).float()
+            for hk in hooks:
+                hk.remove()
+            out["out" + tag] = o[:, :, ::2, ::2].contiguous()
+            for i, b in blocks.items():
+                out["block%d%s" % (i, tag)] = b
+            print("sigma1024", tag or "fp32", "%.0f s" % (time.time() - t0), flush=True)
+    npz("sigma1024_full_ref.npz", **out)
+
+
 def tiny_vae_wrapper():
     """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
     a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
@@ -1139,6 +1241,8 @@ def main():
             xl_depth6(R)
         if "stdit_full" in only:            # ~8 minutes of CPU: only when asked for by name
             stdit_full(R)
+        if "stdit_full_w4a8" in only:       # ~15 minutes of CPU
+            stdit_full_w4a8(R)
         if want("vae"):
             tiny_vae_wrapper()
         if want("attn_kats"):
@@ -1154,6 +1258,8 @@ def main():
             xl_depth6_pixart()
         if want("alpha256_full"):
             alpha256_full()
+        if "sigma1024_full" in only:        # ~6 minutes of CPU: only when asked for by name
+            sigma1024_full()
 
 
 if __name__ == "__main__":

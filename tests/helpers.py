@@ -174,3 +174,27 @@ def stdit_full_inputs(seed: int):
     mask = torch.zeros(1, 120, dtype=torch.int64)
     mask[0, :80] = 1
     return x, y, mask, torch.tensor([577])
+
+
+def seeded_act_scale(name: str, K: int, seed: int, n_ranges: int = 2):
+    """A smooth-quant activation statistic for the layer called ``name`` from a seed alone ([n_ranges, 1, K], positive,
+    fp16-representable: the reference's fp16 mode holds the same values): |N(0,1)| * 1.5 + 0.5 with every 37th channel an
+    outlier (x 12), a different draw per time range - what ``act_quantizer.act_scale`` holds after calibration
+    (quant_layer.py:118-133), injected the way a loaded ckpt.pth would set it."""
+    import zlib
+    g = torch.Generator().manual_seed((int(seed) * 7919 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
+    a = torch.randn(n_ranges, 1, K, generator=g).abs() * 1.5 + 0.5
+    a[:, :, ::37] *= 12.0
+    return a.half().float()
+
+
+def sigma1024_inputs(seed: int):
+    """Inputs of the full-size PixArt-Sigma 1024^2 forward (tests/golden/sigma1024_full_ref.npz) from the seed alone: latents
+    [2, 4, 128, 128] (uncond | cond), prompt embeddings [2, 1, 300, 4096], 300 and 143 prompt tokens kept, timestep 500."""
+    g = torch.Generator().manual_seed(int(seed) + 1)
+    x = torch.randn(2, 4, 128, 128, generator=g).half().float()
+    y = (torch.randn(2, 1, 300, 4096, generator=g) * 0.5).half().float()
+    mask = torch.zeros(2, 300, dtype=torch.int64)
+    mask[0, :300] = 1
+    mask[1, :143] = 1
+    return x, y, mask, torch.tensor([500, 500])
