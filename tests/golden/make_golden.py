@@ -6,6 +6,14 @@ The reference ships no tests and no golden vectors, so parity is p
 of the reference itself, produced here on CPU in fp32 from fp16-representable inputs/weights with
 the third-party stubs of oracle/ref_import.py.  Only data is written: inputs, parameters of tiny
 randomly initialised models, and the reference's outputs.  No reference source text is stored.
+
+The FULL-SIZE vectors (BASELINE.json's configurations at full size and depth; weights and inputs from seeds, the
+reference's outputs subsampled) take minutes of CPU each and are produced only when named:
+    python tests/golden/make_golden.py --only=stdit_full            (~7 min)   -> stdit_full_ref.npz
+    python tests/golden/make_golden.py --only=stdit_full_w4a8       (~18 min)  -> stdit_full_w4a8_ref.npz
+    python tests/golden/make_golden.py --pixart-only --only=sigma1024_full (~6 min) -> sigma1024_full_ref.npz
+(`--pixart-only --only=alpha256_full`, ~70 s, also runs by default).  GOLDEN_OUT=/tmp/x writes elsewhere for a
+reproducibility check.
 """
 from __future__ import annotations
 
