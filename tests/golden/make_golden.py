@@ -11,6 +11,7 @@ The FULL-SIZE vectors (BASELINE.json's configurations at full size and depth; we
 reference's outputs subsampled) take minutes of CPU each and are produced only when named:
     python tests/golden/make_golden.py --only=stdit_full            (~7 min)   -> stdit_full_ref.npz
     python tests/golden/make_golden.py --only=stdit_full_w4a8       (~18 min)  -> stdit_full_w4a8_ref.npz
+    python tests/golden/make_golden.py --only=stdit_full_ddim2      (~20 min)  -> stdit_full_ddim2_ref.npz
     python tests/golden/make_golden.py --pixart-only --only=sigma1024_full (~6 min) -> sigma1024_full_ref.npz
 (`--pixart-only --only=alpha256_full`, ~70 s, also runs by default).  GOLDEN_OUT=/tmp/x writes elsewhere for a
 reproducibility check.
@@ -1156,6 +1157,44 @@ def sigma1024_full():
     npz("sigma1024_full_ref.npz", **out)
 
 
+def stdit_full_ddim2(R):
+    """The headline configuration's SAMPLING LOOP at full size on the reference itself: the model of :func:`stdit_full`
+    (W8A8 dynamic, cfg_split) under the reference's own IDDPM with num_sampling_steps = 2, cfg 4.0, DDIM eta 0 -
+    forward_with_cfg (two B = 1 forwards per step, guidance on 3 of the 4 eps channels, PTQD table zero) and
+    ddim_sample_loop from a seeded latent: four full-size forwards per mode.  Stored: the final latent at every second
+    spatial position, fp32 mode and fp16 mode."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict, stdit_full_inputs
+    import time
+    seed = STDIT_FULL_SEED
+    out = {"seed": np.array(seed)}
+    m = R.STDiT(enable_flashattn=False, input_size=(16, 64, 64), depth=28, hidden_size=1152, num_heads=16, model_max_length=120,
+                caption_channels=4096)
+    m.load_state_dict(seeded_state_dict(m, seed), strict=True)
+    m.eval()
+    x, y, mask, t = stdit_full_inputs(seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    y2 = torch.cat([y, h(torch.randn(1, 1, 120, 4096, generator=g) * 0.5)])      # [cond, null] as the scripts stack them
+    with torch.no_grad():
+        qnn = R.QuantModel(m, ref_import.wq_cfg(8, mixed_precision=[4, 6, 8]), ref_import.aq_cfg(T=16, S=1024, n_prompt=120))
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.fp_layer_list = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+        qnn.set_quant_state(True, False)
+        qnn(x, t, y, mask=mask)
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_init_done("activation")
+        qnn.set_quant_state(True, True)
+        qnn.cfg_split = True
+        for tag, q, yy in (("", qnn, y2), ("_ref_fp16", _half_copy(qnn), y2.half())):
+            t0 = time.time()
+            q.cfg_split = True
+            final, sch = _ddim(q, 2, x, yy, mask)
+            out["final" + tag] = final.float()[:, :, :, ::2, ::2].contiguous()
+            out["timestep_map"] = np.array(sch.timestep_map)
+            print("stdit_full_ddim2", tag or "fp32", "%.0f s" % (time.time() - t0), flush=True)
+    npz("stdit_full_ddim2_ref.npz", **out)
+
+
 def tiny_vae_wrapper():
     """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
     a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
@@ -1251,6 +1290,8 @@ def main():
             stdit_full(R)
         if "stdit_full_w4a8" in only:       # ~15 minutes of CPU
             stdit_full_w4a8(R)
+        if "stdit_full_ddim2" in only:      # ~20 minutes of CPU
+            stdit_full_ddim2(R)
         if want("vae"):
             tiny_vae_wrapper()
         if want("attn_kats"):

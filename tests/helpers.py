@@ -198,3 +198,9 @@ def sigma1024_inputs(seed: int):
     mask[0, :300] = 1
     mask[1, :143] = 1
     return x, y, mask, torch.tensor([500, 500])
+
+
+def stdit_full_null_y(seed: int):
+    """The null-prompt embedding of the full-size two-step DDIM vectors (stdit_full_ddim2_ref.npz): [1, 1, 120, 4096]."""
+    g = torch.Generator().manual_seed(int(seed) + 2)
+    return (torch.randn(1, 1, 120, 4096, generator=g) * 0.5).half().float()
