@@ -12,6 +12,7 @@ reference's outputs subsampled) take minutes of CPU each and are produced only w
     python tests/golden/make_golden.py --only=stdit_full            (~7 min)   -> stdit_full_ref.npz
     python tests/golden/make_golden.py --only=stdit_full_w4a8       (~18 min)  -> stdit_full_w4a8_ref.npz
     python tests/golden/make_golden.py --only=stdit_full_ddim2      (~20 min)  -> stdit_full_ddim2_ref.npz
+    python tests/golden/make_golden.py --only=stdit_full_ptq        (~8 min)   -> stdit_full_ptq_ref.npz
     python tests/golden/make_golden.py --pixart-only --only=sigma1024_full (~6 min) -> sigma1024_full_ref.npz
 (`--pixart-only --only=alpha256_full`, ~70 s, also runs by default).  GOLDEN_OUT=/tmp/x writes elsewhere for a
 reproducibility check.
@@ -1195,6 +1196,52 @@ def stdit_full_ddim2(R):
     npz("stdit_full_ddim2_ref.npz", **out)
 
 
+def stdit_full_ptq(R):
+    """The PTQ PRODUCER at full size on the reference itself (t2v/scripts/ptq.py:207-293 replayed through the reference's
+    classes, as :func:`tiny_stdit` does at hidden 64): the model of :func:`stdit_full` under the W4A8 plan, pass 1 - four FP
+    forwards (t = 999, 721, 400, 61) collecting the momentum |x|-max statistic per smooth-quant time range - and pass 2 - one
+    weight-quantized forward per range start for the weight grids of every bit width.  Stored for eight layers
+    (tests/helpers.py::PTQ_FULL_LAYERS): act_scale, delta_list, zero_point_list."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import PTQ_FULL_LAYERS, seeded_state_dict, stdit_full_calib_inputs
+    import time
+    seed = STDIT_FULL_SEED
+    out = {"seed": np.array(seed)}
+    m = R.STDiT(enable_flashattn=False, input_size=(16, 64, 64), depth=28, hidden_size=1152, num_heads=16, model_max_length=120,
+                caption_channels=4096)
+    m.load_state_dict(seeded_state_dict(m, seed), strict=True)
+    m.eval()
+    xs, ts, cs, masks = stdit_full_calib_inputs(seed)
+    fp = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+    smooth = dict(alpha=[0.11, 0.11], timerange=[[0, 500], [501, 1000]])
+    with torch.no_grad():
+        qnn = R.QuantModel(m, ref_import.wq_cfg(4, mixed_precision=[4, 6, 8]),
+                           ref_import.aq_cfg(T=16, S=1024, n_prompt=120, smooth=smooth))
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.fp_layer_list = list(fp)
+        qnn.cfg_split = True
+        t0 = time.time()
+        qnn.set_quant_state(False, False)
+        qnn.set_smooth_quant(smooth_quant=False, smooth_quant_running_stat=True)
+        for i in range(4):
+            qnn(xs[i:i + 1], ts[i:i + 1], cs[i:i + 1], mask=masks[i:i + 1])
+        print("stdit_full_ptq pass 1 %.0f s" % (time.time() - t0), flush=True)
+        t0 = time.time()
+        qnn.set_smooth_quant(smooth_quant=True, smooth_quant_running_stat=False)
+        qnn.set_layer_smooth_quant(model=qnn, module_name_list=fp, smooth_quant=False, smooth_quant_running_stat=False)
+        qnn.set_quant_state(True, False)
+        for tt in (torch.tensor([0]), torch.tensor([501])):
+            qnn(xs[:1], tt, cs[:1], mask=masks[:1])
+        print("stdit_full_ptq pass 2 %.0f s" % (time.time() - t0), flush=True)
+        mods = dict(qnn.model.named_modules())
+        for name in PTQ_FULL_LAYERS:
+            layer = mods[name]
+            out["%s/act_scale" % name] = layer.act_quantizer.act_scale.detach().float().clone()
+            out["%s/delta_list" % name] = layer.weight_quantizer.delta_list.detach().float().clone()
+            out["%s/zero_point_list" % name] = layer.weight_quantizer.zero_point_list.detach().float().clone()
+    npz("stdit_full_ptq_ref.npz", **out)
+
+
 def tiny_vae_wrapper():
     """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
     a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
@@ -1292,6 +1339,8 @@ def main():
             stdit_full_w4a8(R)
         if "stdit_full_ddim2" in only:      # ~20 minutes of CPU
             stdit_full_ddim2(R)
+        if "stdit_full_ptq" in only:        # ~8 minutes of CPU
+            stdit_full_ptq(R)
         if want("vae"):
             tiny_vae_wrapper()
         if want("attn_kats"):

@@ -204,3 +204,20 @@ def stdit_full_null_y(seed: int):
     """The null-prompt embedding of the full-size two-step DDIM vectors (stdit_full_ddim2_ref.npz): [1, 1, 120, 4096]."""
     g = torch.Generator().manual_seed(int(seed) + 2)
     return (torch.randn(1, 1, 120, 4096, generator=g) * 0.5).half().float()
+
+
+PTQ_FULL_LAYERS = ["blocks.0.attn.q", "blocks.0.attn_temp.proj", "blocks.0.mlp.fc2", "blocks.13.cross_attn.q_linear",
+                   "blocks.13.cross_attn.kv_linear", "blocks.13.mlp.fc1", "blocks.27.attn.proj", "blocks.27.mlp.fc2"]
+
+
+def stdit_full_calib_inputs(seed: int):
+    """The four calibration samples of the full-size PTQ vectors (stdit_full_ptq_ref.npz) from the seed alone: latents
+    [4, 4, 16, 64, 64], prompt embeddings [4, 1, 120, 4096], masks keeping 80 / 33 / 120 / 57 tokens, timesteps
+    999 / 721 / 400 / 61 (two per smooth-quant time range)."""
+    g = torch.Generator().manual_seed(int(seed) + 3)
+    xs = torch.randn(4, 4, 16, 64, 64, generator=g).half().float()
+    cs = (torch.randn(4, 1, 120, 4096, generator=g) * 0.5).half().float()
+    masks = torch.zeros(4, 120, dtype=torch.int64)
+    for i, n in enumerate((80, 33, 120, 57)):
+        masks[i, :n] = 1
+    return xs, torch.tensor([999, 721, 400, 61]), cs, masks
