@@ -11,7 +11,6 @@ and dequantized / GEMM outputs within the tolerance stated in each test.
 """
 from __future__ import annotations
 
-import math
 from typing import Optional, Sequence, Tuple
 
 import torch

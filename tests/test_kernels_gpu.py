@@ -3,7 +3,6 @@
 Integer codes / per-row integer terms are compared bit-exactly; floating outputs within the
 tolerance written next to each assert (fp16 output rounding is 2^-11 relative).
 """
-import math
 
 import pytest
 import torch

@@ -15,7 +15,6 @@ import warnings
 import torch
 import torch.nn as nn
 
-from ... import ops
 from ..quantizer.base_quantizer import ActQuantizer, BaseQuantizer, StraightThrough, WeightQuantizer
 from .dit_quant_layer import QuantAttnLinearImg, QuantCrossAttnLinearImg
 from .quant_block import BaseQuantBlock, get_specials

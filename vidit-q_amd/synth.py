@@ -15,7 +15,6 @@ import torch
 
 from .config import QuantConfig, to_config
 from .qdiff.models.quant_model import QuantModel
-from .qdiff.models.quant_layer import QuantLayer
 from .t2v.stdit import STDiT
 
 REMAIN_FP = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]   # remain_fp.txt

@@ -18,7 +18,6 @@ is the first half of the duplicated batch; PTQD ``1/(1+k)`` with k looked up by 
 """
 from __future__ import annotations
 
-import math
 from typing import Optional
 
 import numpy as np
