@@ -401,3 +401,35 @@ def test_fp_edge_and_gelu_one_pass_routing_decisions():
     assert fc2.gelu_one_pass_ok(1, fc2.in_features, None) and fc2.gelu_one_pass_ok(1, fc2.in_features, s)
     assert fc2.gelu_one_pass_ok(2, fc2.in_features, None) and fc2.gelu_one_pass_ok(2, 4608, s)
     assert not fc2.gelu_one_pass_ok(2, 1152, s) and not fc2.gelu_one_pass_ok(3, 4608, None)
+
+
+def test_seeded_inputs_and_weights_reproduce_their_recorded_checksums():
+    """The full-size vectors of tests/golden/ store SEEDS, not weights or inputs: the tests redraw them with torch's CPU
+    generator (tests/helpers.py).  If a torch build drew different numbers, every full-size parity test would fail far
+    from its cause - this check fails first and says why.  Checksums recorded in the authoring container
+    (sum, sum |x|, a position-weighted sum)."""
+    from helpers import (alpha256_inputs, seeded_act_scale, seeded_state_dict, sigma1024_inputs, stdit_full_calib_inputs,
+                         stdit_full_inputs, stdit_full_null_y)
+
+    def cs(t):
+        t = t.double()
+        w = torch.arange(t.numel(), dtype=torch.float64).reshape(t.shape).remainder(97)
+        return (float(t.sum()), float(t.abs().sum()), float((t * w).sum()))
+
+    def same(got, want):
+        assert all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip(got, want)), (got, want)
+    x, y, _, _ = stdit_full_inputs(5501)
+    same(cs(x), (180.167041182518, 208888.15141177177, 8831.83563297987))
+    same(cs(y), (-30.934920966625214, 196223.42003315687, -5435.354550182819))
+    z, y, n, _ = alpha256_inputs(4301)
+    same(cs(z), (102.12994819879532, 3247.4124308228493, 2991.799762606621))
+    same(cs(n), (-880.6551586389542, 196000.67790842056, -38484.38274502754))
+    x, y, _, _ = sigma1024_inputs(6601)
+    same(cs(y), (-1259.7143214344978, 980611.6273691058, -65609.97348415852))
+    xs, _, c, _ = stdit_full_calib_inputs(5501)
+    same(cs(xs), (-420.43513721227646, 837382.8847548366, 2739.407063126564))
+    same(cs(seeded_act_scale("blocks.3.mlp.fc2", 4608, 5501)), (20307.30615234375, 20307.30615234375, 987386.8154296875))
+    same(cs(stdit_full_null_y(5501)), (-70.74934846162796, 196082.59859234095, 8845.263318419456))
+    sd = seeded_state_dict(torch.nn.Linear(1152, 1152), 5501)
+    same(cs(sd["weight"]), (48.5724156498909, 31172.122928082943, 2118.53741645813))
+    same(cs(sd["bias"]), (-0.3803201913833618, 17.906386017799377, -9.180069327354431))
