@@ -13,6 +13,7 @@ reference's outputs subsampled) take minutes of CPU each and are produced only w
     python tests/golden/make_golden.py --only=stdit_full_w4a8       (~18 min)  -> stdit_full_w4a8_ref.npz
     python tests/golden/make_golden.py --only=stdit_full_ddim2      (~20 min)  -> stdit_full_ddim2_ref.npz
     python tests/golden/make_golden.py --only=stdit_full_ptq        (~8 min)   -> stdit_full_ptq_ref.npz
+    python tests/golden/make_golden.py --only=stdit_full_static     (~20 min)  -> stdit_full_static_ref.npz
     python tests/golden/make_golden.py --pixart-only --only=sigma1024_full (~6 min) -> sigma1024_full_ref.npz
 (`--pixart-only --only=alpha256_full`, ~70 s, also runs by default).  GOLDEN_OUT=/tmp/x writes elsewhere for a
 reproducibility check.
@@ -1242,6 +1243,62 @@ def stdit_full_ptq(R):
     npz("stdit_full_ptq_ref.npz", **out)
 
 
+def stdit_full_static(R):
+    """The static tensor-wise plan (w8a8_naive.yaml: ``per_group: False, dynamic: False``, cfg_split False) at FULL SIZE on the
+    reference itself: the model of :func:`stdit_full`; weight grids from one weight-quantized B = 2 forward, activation
+    grids calibrated on one (cond | uncond) batch at t = 900 (ptq.py:296-318: every batch re-initialises them), then ONE
+    joint B = 2 forward (32768 token rows) at t = 721 on other inputs, fp32 mode and fp16 mode.  Stored: the calibrated
+    (delta, zero_point) scalar of every activation quantizer, every 512th token row of block 27 and the output at every
+    second frame / spatial position."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import seeded_state_dict, stdit_full_calib_inputs, stdit_full_inputs, stdit_full_null_y
+    import time
+    seed = STDIT_FULL_SEED
+    out = {"seed": np.array(seed)}
+    m = R.STDiT(enable_flashattn=False, input_size=(16, 64, 64), depth=28, hidden_size=1152, num_heads=16, model_max_length=120,
+                caption_channels=4096)
+    m.load_state_dict(seeded_state_dict(m, seed), strict=True)
+    m.eval()
+    fp = ["x_embedder", "t_block", "t_embedder", "y_embedder", "final_layer"]
+    xs, _, cs, masks = stdit_full_calib_inputs(seed)
+    cx, cc, cm, ct = torch.cat([xs[:1], xs[:1]]), cs[:2], masks[:1], torch.tensor([900, 900])
+    x, y, mask, _ = stdit_full_inputs(seed)
+    x2, y2, t2 = torch.cat([x, x]), torch.cat([y, stdit_full_null_y(seed)]), torch.tensor([721, 721])
+    with torch.no_grad():
+        qnn = R.QuantModel(m, ref_import.wq_cfg(8, mixed_precision=[4, 6, 8]),
+                           ref_import.aq_cfg(dynamic=False, per_group=False, T=16, S=1024, n_prompt=120))
+        qnn.set_module_name_for_quantizer(qnn.model)
+        qnn.cfg_split = False
+        t0 = time.time()
+        qnn.set_quant_state(True, False)
+        qnn.set_layer_quant(model=qnn, module_name_list=fp, quant_level="per_layer", weight_quant=False, act_quant=False, prefix="")
+        qnn(cx, ct, cc, mask=cm)
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_state(True, True)
+        qnn.set_layer_quant(model=qnn, module_name_list=fp, quant_level="per_layer", weight_quant=False, act_quant=False, prefix="")
+        qnn(cx, ct, cc, mask=cm)
+        qnn.set_quant_init_done("activation")
+        print("stdit_full_static calibration %.0f s" % (time.time() - t0), flush=True)
+        n_act = 0
+        for name, mod in qnn.model.named_modules():
+            if isinstance(mod, R.QuantLayer) and not any(name.startswith(f) for f in fp):
+                out["act/%s/delta" % name] = mod.act_quantizer.delta.detach().float().reshape(-1).clone()
+                out["act/%s/zero_point" % name] = mod.act_quantizer.zero_point.detach().float().reshape(-1).clone()
+                n_act += 1
+        assert n_act == 13 * 28, n_act
+        for tag, q, yy in (("", qnn, y2), ("_ref_fp16", _half_copy(qnn), y2.half())):
+            t0 = time.time()
+            blocks = {}
+            hk = q.model.blocks[27].register_forward_hook(
+                lambda mod, inp, o: blocks.__setitem__(27, o.detach().float()[:, ::512].clone()))
+            o = q(x2, t2, yy, mask=mask).float()
+            hk.remove()
+            out["joint_t721_out" + tag] = o[:, :, ::2, ::2, ::2].contiguous()
+            out["joint_t721_block27" + tag] = blocks[27]
+            print("stdit_full_static", tag or "fp32", "%.0f s" % (time.time() - t0), flush=True)
+    npz("stdit_full_static_ref.npz", **out)
+
+
 def tiny_vae_wrapper():
     """The reference's VideoAutoencoderKL (vae.py:9-57) around a deterministic toy image VAE (diffusers' AutoencoderKL is
     a third-party dependency that is not available): pins the wrapper - frame flattening, micro-batching, the 0.18215
@@ -1341,6 +1398,8 @@ def main():
             stdit_full_ddim2(R)
         if "stdit_full_ptq" in only:        # ~8 minutes of CPU
             stdit_full_ptq(R)
+        if "stdit_full_static" in only:     # ~20 minutes of CPU
+            stdit_full_static(R)
         if want("vae"):
             tiny_vae_wrapper()
         if want("attn_kats"):
