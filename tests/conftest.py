@@ -32,6 +32,23 @@ def pytest_runtest_logreport(report):
         _RUN[report.outcome if report.outcome in ("passed", "failed", "skipped") else "failed"].append(report.nodeid)
 
 
+ORACLE_THREADS = 24     # tools/oracle_threads.py on the GPU box (256 hardware threads, torch default 128): one full-size oracle
+#                         block takes 6.7 s on 128 threads, 3.6 on 64, 2.7 on 32, 2.3 on 24, 2.9 on 16, 3.3 on 8
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The CPU oracle (and every torch CPU reference of the kernel tests) is memory-bound elementwise work plus mid-size
+    GEMMs: torch's default of one thread per core is ~3 x SLOWER than 24 threads on the GPU box's host.  Capped here so
+    that the full-depth oracle tests take ~75 s each instead of ~220 s of the driver's 1200 s limit."""
+    import torch
+    n0 = torch.get_num_threads()
+    if n0 > ORACLE_THREADS:
+        torch.set_num_threads(ORACLE_THREADS)
+    yield
+    torch.set_num_threads(n0)
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch
