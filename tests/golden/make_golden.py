@@ -16,7 +16,8 @@ reference's outputs subsampled) take minutes of CPU each and are produced only w
     python tests/golden/make_golden.py --only=stdit_full_static     (~20 min)  -> stdit_full_static_ref.npz
     python tests/golden/make_golden.py --pixart-only --only=sigma1024_full (~6 min) -> sigma1024_full_ref.npz
 (`--pixart-only --only=alpha256_full`, ~70 s, also runs by default).  GOLDEN_OUT=/tmp/x writes elsewhere for a
-reproducibility check.
+reproducibility check: alpha256_full and stdit_full were regenerated that way in the authoring container (8 threads) and
+came out bit-identical, every array; with another thread count torch's CPU GEMMs may sum in another order.
 """
 from __future__ import annotations
 
