@@ -27,8 +27,182 @@ sys.path.insert(0, ROOT)
 
 PEAK_INT8 = 5.03e15      # dense int8 MFMA ops/s, 256 CU x 2.4 GHz x 8192 op/clk/CU (MI355X_MICROARCH.md / datasheet)
 PEAK_HBM = 8.0e12
+MP_SAMPLING = 20          # the mixed-precision plan's schedule: ONE constant for the widths that travel in the broadcast
+                          # (stdit_legs) and the config applied per step range (_measure_plan) - they must name the same layers
+EXTRA_STEPS, EXTRA_WARMUP = 10, 3     # timed steps / warm-ups of the `extras` legs (4 / 2 until round 4: too short to be stable)
 GEMM_KERNEL = ("gemm_i8_wide_kernel<256,288,4,2,EPI,stagger> (W8A8 Linear: int8 MFMA 16x16x64, full-line LDS-DMA double "
                "buffer, fused dequant epilogue)")
+
+
+
+# --------------------------------------------------------------------------- telemetry (round 5)
+# The driver's number is taken on a box of its own; kernels that did not change have come out 6-14 % apart between boxes.
+# Every leg therefore records what the part was doing: board power, shader clock and temperature before / during / after
+# (amdgpu sysfs hwmon where the container exposes it, `rocm-smi --json` otherwise), and the clock the GEMM itself ran at
+# (one stamped launch behind a back-to-back burst: shader cycle counter against the chip's 100 MHz wall clock).
+def _sysfs_gpu(index):
+    """hwmon files of the index-th amdgpu device, or None"""
+    import glob
+    cards = []
+    for dev_dir in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if open(os.path.join(dev_dir, "vendor")).read().strip() != "0x1002":
+                continue
+        except OSError:
+            continue
+        hw = sorted(glob.glob(os.path.join(dev_dir, "hwmon", "hwmon*")))
+        if hw:
+            cards.append((dev_dir, hw[0]))
+    if not cards:
+        return None
+    dev_dir, hw = cards[index % len(cards)]
+    f = {}
+    for key, names in (("power_w", ("power1_average", "power1_input")), ("sclk_mhz", ("freq1_input",)),
+                       ("mclk_mhz", ("freq2_input",)), ("temp_c", ("temp2_input", "temp1_input"))):
+        for n in names:
+            if os.path.exists(os.path.join(hw, n)):
+                f[key] = os.path.join(hw, n)
+                break
+    return f or None
+
+
+def _read_sysfs(files):
+    out = {}
+    for k, path in files.items():
+        try:
+            v = float(open(path).read().strip())
+        except (OSError, ValueError):
+            continue
+        out[k] = v / 1e6 if k in ("power_w", "sclk_mhz", "mclk_mhz") else v / 1e3
+    return out
+
+
+def _rocm_smi(index):
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"error": "no rocm-smi"}
+    try:
+        r = subprocess.run([exe, "-d", str(index), "--showpower", "--showclocks", "--showtemp", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    out = {}
+    import re
+    for k, v in card.items():
+        kl = k.lower()
+        m = re.search(r"-?\d+(\.\d+)?", str(v))
+        if not m:
+            continue
+        x = float(m.group(0))
+        if "power" in kl and "power_w" not in out:
+            out["power_w"] = x
+        elif kl.startswith("sclk") and "sclk_mhz" not in out:
+            out["sclk_mhz"] = x
+        elif kl.startswith("mclk") and "mclk_mhz" not in out:
+            out["mclk_mhz"] = x
+        elif "temperature" in kl and ("junction" in kl or "temp_c" not in out):
+            out["temp_c"] = x
+    return out or {"error": "unparsed", "keys": sorted(card)[:12]}
+
+
+class Telemetry:
+    """snapshot(): one reading; start() / stop(): a 20 Hz sysfs sampler thread around a timed region (sysfs only: a
+    rocm-smi process per sample would perturb what it measures)."""
+
+    def __init__(self, index):
+        self.index = index
+        self.files = _sysfs_gpu(index)
+        self.source = "sysfs hwmon" if self.files else "rocm-smi"
+        self._stop = None
+        self._rows = []
+
+    def snapshot(self):
+        return _read_sysfs(self.files) if self.files else _rocm_smi(self.index)
+
+    def start(self):
+        if not self.files:
+            return
+        import threading
+        self._rows = []
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                self._rows.append(_read_sysfs(self.files))
+                self._stop.wait(0.05)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self._stop is None:
+            return None
+        self._stop.set()
+        self._th.join()
+        self._stop = None
+        rows = [r for r in self._rows if r]
+        if not rows:
+            return None
+        out = {"samples": len(rows)}
+        for k in rows[0]:
+            v = [r[k] for r in rows if k in r]
+            out[k] = {"min": min(v), "mean": sum(v) / len(v), "max": max(v)}
+        return out
+
+
+_CLOCK_PROBE = {}
+TEL = None          # Telemetry of this rank's device, set in main()
+
+
+def gemm_clock_probe(dev, burst=24):
+    """The shader clock UNDER the GEMM on this box, now: `burst` back-to-back launches of the qkv shape (16384 x 3456 x
+    1152, ~75 us each), then one stamped launch of the same problem (ops.gemm_i8_stamped)."""
+    from viditq_amd import ops
+    if "qa" not in _CLOCK_PROBE:
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(1, 16384, 1152, generator=g).half().to(dev)
+        W = (torch.randn(3456, 1152, generator=g) * 0.03).half().to(dev)
+        d, z = ops.weight_minmax(W, 8)
+        _CLOCK_PROBE.update(qa=ops.rowquant(x), pw=ops.pack_weight(W, d, z, 8),
+                            out=torch.empty((16384, 3456), dtype=torch.float16, device=dev))
+    qa, pw, out = _CLOCK_PROBE["qa"], _CLOCK_PROBE["pw"], _CLOCK_PROBE["out"]
+    try:
+        for _ in range(burst):
+            ops.gemm_i8(qa, pw, out=out, variant=11)
+        _, st = ops.gemm_i8_stamped(qa, pw)
+        torch.cuda.synchronize()
+        t = ops.shader_clock_ghz(st)
+        return {"ghz": round(t["ghz"], 3), "tile_cycles": round(t["tile_cycles"]), "launch_span_us": round(t["launch_span_us"], 1),
+                "phase_cycles": {k: round(v) for k, v in t["phase_cycles"].items()},
+                "how": "%d back-to-back qkv-shape launches, then one stamped launch: shader cycle counter / 100 MHz wall clock, "
+                       "median over the 6144 waves" % burst}
+    except Exception as e:  # noqa: BLE001  (telemetry must never lose the line)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def leg_telemetry(tel, before, during, dev):
+    """what a leg records: readings before / during / after its timed region + the GEMM's own clock right after it"""
+    clock = gemm_clock_probe(dev)
+    return {"source": tel.source, "before": before, "during_timed_region": during, "after": tel.snapshot(),
+            "gemm_shader_clock": clock}
+
+
+
+def collective_info(dist, rehearsal):
+    if dist is None:
+        return {"backend": None, "note": "one rank: no process group"}
+    out = {"backend": "gloo (rehearsal)" if rehearsal else "nccl = RCCL", "torch": torch.__version__,
+           "hip": getattr(torch.version, "hip", None)}
+    try:
+        out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:  # noqa: BLE001
+        out["rccl_version"] = "unavailable: %s" % type(e).__name__
+    for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_P2P_DISABLE", "RCCL_MSCCL_ENABLE"):
+        if k in os.environ:
+            out.setdefault("env", {})[k] = os.environ[k]
+    return out
 
 
 def parse():
@@ -44,6 +218,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the W4A8 / W4A8-MP / PixArt-Sigma legs")
+    ap.add_argument("--no-telemetry", action="store_true", help="no power / clock / temperature sampling, no stamped GEMM launch")
     ap.add_argument("--gemm-variant", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="eager launches in the timed region (no HIP graph)")
     ap.add_argument("--one-stream", action="store_true", help="cond and uncond serialised on one stream")
@@ -187,7 +362,7 @@ def stdit_legs(a, dev, rank, world, plans, steps, warmup, dist=None, events=True
         model = synth.build_stdit(dev, depth=a.depth)
         # a plan that switches bit widths per step range names them up front: they travel in the one broadcast, and
         # ranks > 0 (which drop their fp16 master weights) never have to re-pack
-        mp_w = synth.synthetic_mp_config(model, 20)[0] if "w4a8_mp" in plans else None
+        mp_w = synth.synthetic_mp_config(model, MP_SAMPLING)[0] if "w4a8_mp" in plans else None
         qnn = shard.quantize_and_distribute(model, cfg, rank, world, mp_weight_cfg=mp_w)   # rank 0 calibrates + packs, RCCL broadcast
         assert all(b.fused_ok() for b in qnn.model.blocks), "hot path must be the fused HIP route"
         for plan in plans:
@@ -203,7 +378,7 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
     from viditq_amd import graph, ops, synth
     from viditq_amd.t2v import IDDPM
     res = {}
-    n_sampling = 20 if plan == "w4a8_mp" else 100
+    n_sampling = MP_SAMPLING if plan == "w4a8_mp" else 100
     sch = IDDPM(num_sampling_steps=n_sampling, cfg_scale=4.0)
     mp = None
     if plan == "w4a8_mp":
@@ -240,6 +415,8 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
         return out, x
 
     el = 0.0
+    host_enqueue = 0.0
+    tel_before = None
     for n_done, pi in enumerate(mine):
         # a prompt's token selection is baked into its captured graphs: each prompt captures its own (untimed, as the
         # reference's per-prompt set-up is), then runs W warm-up and K timed steps
@@ -259,14 +436,21 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
         if dist is not None and n_done == 0:
             dist.barrier()
         torch.cuda.synchronize()
+        if TEL is not None and n_done == 0:
+            tel_before = TEL.snapshot()
+            TEL.start()
         t0 = time.perf_counter()
         for j in range(warmup, warmup + steps):
             x, buf = step(j, x, buf)
+        t_enq = time.perf_counter() - t0                # host done enqueueing (graph replays: a few ms; eager: the launch rate)
         torch.cuda.synchronize()
         if dist is not None and n_done == len(mine) - 1:
             dist.barrier()
             torch.cuda.synchronize()
         el += time.perf_counter() - t0
+        host_enqueue += t_enq
+        if TEL is not None and n_done == len(mine) - 1:
+            res["telemetry"] = leg_telemetry(TEL, tel_before, TEL.stop(), dev)
         if n_done < len(mine) - 1:
             gs = None                                   # frees this prompt's graphs before the next capture
     assert torch.isfinite(x).all()
@@ -304,11 +488,12 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
         qnn.model.set_prompt_cache(False)
     gs = None
     res.update(el=el, steps=steps * len(mine), n_sampling=n_sampling, cached=cached, n_prompts=n_prompts, prompts_here=len(mine),
+           host_enqueue_ms_per_step=host_enqueue / (steps * len(mine)) * 1e3,
            roofline=gemm_roofline(timing, el / len(mine), plan == "w8a8") if timing else None)
     return res
 
 
-def pixart_leg(dev, steps=4, w_bits=4, size=1024, Lp=300):
+def pixart_leg(dev, steps=10, w_bits=4, size=1024, Lp=300, warmup=3):
     """BASELINE config 5 as a timing leg: PixArt-Sigma 1024^2 (4096 tokens, prompts of up to 300 tokens), 4-bit weights,
     dynamic per-token 8-bit activations, DPM-Solver++ 2M, cfg 4.5, the t2i loop's ONE batched (uncond | cond) forward
     per step (quant_txt2img.py:130-153; B = 2: token scales shared over the pair as base_quantizer.py:185 does)."""
@@ -343,12 +528,17 @@ def pixart_leg(dev, steps=4, w_bits=4, size=1024, Lp=300):
         # replayed as a HIP graph (graph.GraphedModel) the step takes the same time (49.7 vs 50.3 steps/s)
         solver = DPMS_sigma(qnn.forward_with_dpmsolver, condition=y, uncondition=null_y, cfg_scale=4.5,
                             model_kwargs=dict(data_info=None, mask=mask))
-        solver.sample(z, steps=2, order=2)                     # warm-up: packing, caches
+        solver.sample(z, steps=warmup, order=2)                # warm-up: packing, caches
         torch.cuda.synchronize()
+        tel_before = TEL.snapshot() if TEL is not None else None
+        if TEL is not None:
+            TEL.start()
         t0 = time.perf_counter()
         out = solver.sample(z, steps=steps, order=2)
+        t_enq = time.perf_counter() - t0                       # eager launches: the host's enqueue time (GPU-bound iff < el)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        telemetry = leg_telemetry(TEL, tel_before, TEL.stop(), dev) if TEL is not None else None
         assert torch.isfinite(out).all()
         timing = []
         ops.GEMM_TIMING = timing
@@ -366,7 +556,8 @@ def pixart_leg(dev, steps=4, w_bits=4, size=1024, Lp=300):
                         "blocks.27.mlp.fc2 smoothed with a running statistic (quant_txt2img.py:297-300): that layer is "
                         "parity-tested (tiny_pixart_w4a8) but not part of this timing"
                         % (size, size, w_bits, (lat // 2) ** 2, Lp, w_bits),
-            "value": steps / el, "unit": "sampling steps/s", "steps": steps, "ms_per_step": el / steps * 1e3,
+            "value": steps / el, "unit": "sampling steps/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+            "host_enqueue_ms_per_step": t_enq / steps * 1e3, "telemetry": telemetry,
             "status_word": status, "gemm_frac_of_int8_peak": roof["frac"], "gemm_avg_launch_us": roof["avg_launch_us"]}
 
 
@@ -435,6 +626,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if a.gemm_variant is not None:
         ops.DEFAULT_GEMM_VARIANT = a.gemm_variant
+    global TEL
+    if rank == 0 and not a.no_telemetry:
+        TEL = Telemetry(local)
 
     head = stdit_legs(a, dev, rank, world, [a.plan], a.steps, a.warmup, dist=dist, events=not a.no_roofline_events)[0]
     el = head["el"]
@@ -446,15 +640,26 @@ def main():
         per_rank = [float(t.item()) for t in every]
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
     el_max = float(el_t.item())
+    # N > 1 self-diagnosis: every rank's own time inside the weight broadcast (the receivers block until rank 0 has
+    # calibrated and packed, so a slow link and a slow rank 0 look different here) and the collective library's version
+    bc_rank = None
+    if dist is not None:
+        bc = head.get("broadcast") or {}
+        bc_t = torch.tensor([float(bc.get("seconds", -1.0))], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(bc_t) for _ in range(world)]
+        dist.all_gather(every, bc_t)
+        bc_rank = [float(t.item()) for t in every]
 
     extras = None
     if rank == 0 and world == 1 and a.plan == "w8a8" and not a.no_extras and a.depth == 28 and not a.prompts:
         extras = {}
         # a leg that fails reports its error; the headline line above is already measured and is printed regardless
         try:
-            legs = stdit_legs(a, dev, 0, 1, ["w4a8", "w4a8_mp"], 4, 2, events=not a.no_roofline_events, hoisted=False)
+            legs = stdit_legs(a, dev, 0, 1, ["w4a8", "w4a8_mp"], EXTRA_STEPS, EXTRA_WARMUP, events=not a.no_roofline_events,
+                              hoisted=False)
             for plan, r in zip(("w4a8", "w4a8_mp"), legs):
-                extras[plan] = {"value": r["steps"] / r["el"], "unit": "denoising steps/s", "steps": r["steps"], "warmup": 2,
+                extras[plan] = {"value": r["steps"] / r["el"], "unit": "denoising steps/s", "steps": r["steps"], "warmup": EXTRA_WARMUP,
+                                "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"], "telemetry": r.get("telemetry"),
                                 "ms_per_step": r["el"] / r["steps"] * 1e3, "schedule": "DDIM-%d" % r["n_sampling"],
                                 "status_word": r["status"],
                                 "gemm_frac_of_int8_peak": r["roofline"]["frac"] if r["roofline"] else None,
@@ -495,10 +700,16 @@ def main():
                            "cond_uncond_streams": 1 if (a.one_stream or a.no_graph) else 2},
                 # self-diagnosis of a multi-GPU run: every rank's own rate, and what the one set-up collective moved
                 "per_rank_steps_per_s": [k / t for k, t in zip(steps_of, per_rank)],
-                "weights_broadcast": head["broadcast"],
+                "weights_broadcast": (dict(head["broadcast"], per_rank_seconds=bc_rank) if head["broadcast"] and bc_rank
+                                      else head["broadcast"]),
+                "collectives": collective_info(dist, rehearsal),
                 "prompt_invariants_hoisted": head["cached"],
                 "whole_step_int8_frac": 43.87e12 * (a.depth / 28.0) * value / world / PEAK_INT8,
                 "roofline": head["roofline"],
+                # what the part was doing during THIS leg (power / shader clock / temperature before, during and after the
+                # timed region; the clock the GEMM itself ran at right after it) and how far ahead of the GPU the host was
+                "telemetry": head.get("telemetry"),
+                "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
                 "extras": extras}
         if rehearsal:
             line["rehearsal"] = "ranks share devices, gloo backend: control-flow dry run, NOT a measurement"

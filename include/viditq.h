@@ -187,6 +187,18 @@ int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32
                int rows_per_gate, int M, int N, int K, int Kp, int w_bits, int epilogue,
                int variant, void* stream);
 
+/* Diagnostics (bench telemetry, no reference counterpart): ONE launch of the default 8-bit kernel (256 x 288 tile,
+ * plain epilogue) whose waves also stamp the shader cycle counter and the chip's 100 MHz wall clock - what clock the
+ * GEMM actually ran at on THIS box (bench.py reports it beside every rate; a power-bound part runs 1.8-2.1 of its
+ * nominal 2.4 GHz).  stamps [tiles][8 waves][10] int64, tiles = ceil(M/256) * ceil(N/288): 0-6 shader cycles at entry /
+ * first stage landed / main loop end / parameters staged / slabs written / stores issued / stores drained, 7 and 8 the
+ * wall clock at entry and exit (10 ns ticks), 9 unused.  n_stamps = capacity of `stamps` in int64 (VQ_ESHAPE when
+ * too small).  Outputs equal vq_gemm_i8(..., w_bits 8, VQ_EPI_NONE). */
+int vq_gemm_i8_stamped(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R,
+                       const void* wq, const float* sw, const int32_t* zw, const int32_t* cs,
+                       const float* bias, void* out, int ldo, int M, int N, int K, int Kp,
+                       void* stamps, long n_stamps, void* stream);
+
 /* Batched form of vq_gemm_i8 for ONE activation and nbatch stacked weight sets:
  *   out[b] [M, N] fp16 = dequant(xq . wq[b]^T) + bias[b],   b = 0 .. nbatch-1
  * wq [nbatch, N, Kp] int8, sw / zw / cs / bias [nbatch, N], out [nbatch, M, N] contiguous.  Used for the kv_linear of

@@ -111,7 +111,7 @@ def test_every_entry_point_rejects_null_and_bad_shapes_without_gpu():
     # a zero extent with non-null pointers (position of one size parameter per entry point)
     zero_size = {"vq_rowquant": 15, "vq_gelu_rowquant": 8, "vq_ln_modulate_rowquant": 13, "vq_rowquant_smooth_multi": 8,
                  "vq_smooth_reciprocal": 2, "vq_fakequant_act": 9, "vq_epsfill_fixup": 7, "vq_pack_weight": 8,
-                 "vq_weight_minmax": 4, "vq_gemm_i8": 14, "vq_gemm_i8_batched": 11, "vq_gemm_i8_grouped": 12,
+                 "vq_weight_minmax": 4, "vq_gemm_i8": 14, "vq_gemm_i8_stamped": 11, "vq_gemm_i8_batched": 11, "vq_gemm_i8_grouped": 12,
                  "vq_attn_fwd": 5, "vq_attn_temporal": 6, "vq_attn_temporal_rowquant": 13, "vq_adaln_table": 4,
                  "vq_linear_f16": 4, "vq_cfg_ddim_step": 4}
     for name, pos in zero_size.items():
@@ -128,6 +128,7 @@ def test_every_entry_point_rejects_null_and_bad_shapes_without_gpu():
         "vq_pack_weight": ({8: 4, 9: 64, 10: 64, 11: 8}, -2),                        # Kp % 128
         "vq_gemm_i8": ({10: 64, 13: 1, 14: 4, 15: 62, 16: 64, 17: 128, 18: 8, 19: 0, 20: 0}, -2),       # N % 4
         "vq_gemm_i8_batched": ({10: 1, 11: 4, 12: 64, 13: 64, 14: 120, 15: 8}, -2),
+        "vq_gemm_i8_stamped": ({10: 64, 11: 4, 12: 64, 13: 64, 14: 120}, -2),         # Kp % 128
         "vq_gemm_i8_grouped": ({0: 2, 11: 64, 12: 4, 13: 64, 14: 64, 15: 128, 16: 8}, -2),             # ldo < 2 N
         "vq_attn_temporal": ({4: 1, 5: 17, 6: 4, 7: 4, 8: 72}, -2),                  # T > 16
         "vq_attn_temporal_rowquant": ({11: 1, 12: 16, 13: 4, 14: 4, 15: 72, 17: 100}, -2),
@@ -137,6 +138,8 @@ def test_every_entry_point_rejects_null_and_bad_shapes_without_gpu():
         longs = {i: 128 for i, ct in enumerate(_lib.SIGNATURES[name][1]) if ct is ctypes.c_long}
         assert getattr(lib, name)(*_args(name, one, ints=ints, longs=longs)) == code, name
     assert lib.vq_attn_fwd(*_args("vq_attn_fwd", one, ints={4: 1, 5: 4, 6: 4, 7: 1, 8: 72}, longs={10: 12})) == -2   # row % 8
+    assert lib.vq_gemm_i8_stamped(*_args("vq_gemm_i8_stamped", one, ints={10: 64, 11: 300, 12: 64, 13: 64, 14: 128},
+                                         longs={16: 159})) == -2            # two tiles need 160 stamps
     unsup = {
         "vq_rowquant": {14: 1, 15: 4, 16: 64, 17: 128, 18: 9},
         "vq_gelu_rowquant": {7: 3, 8: 4, 9: 64, 10: 128, 11: 8},                    # B > 2: GEMM epilogue route
@@ -186,6 +189,11 @@ def test_product_ops_refuse_cpu_tensors():
         "adaln_table": lambda: ops.adaln_table(h(6, 64), h(1, 384)),
         "linear_f16": lambda: ops.linear_f16(h(4, 64), h(8, 64)),
         "cfg_ddim_step": lambda: ops.cfg_ddim_step(f(1, 8, 4), f(1, 8, 4), f(1, 4, 4), 4.0, 1.0, 1.0, 1.0, 0.5),
+        "gemm_i8_stamped": lambda: ops.gemm_i8_stamped(
+            ops.QAct(torch.zeros(4, 128, dtype=torch.int8), f(4), torch.zeros(4, dtype=torch.int32),
+                     torch.zeros(4, dtype=torch.int32), 64, 8),
+            ops.PackedWeight(torch.zeros(8, 128, dtype=torch.int8), f(8), torch.zeros(8, dtype=torch.int32),
+                             torch.zeros(8, dtype=torch.int32), 8, 64, 128, 8)),
         "smooth_rcp": lambda: ops.smooth_rcp(f(64)),
         "smooth_div_check": lambda: ops.smooth_div_check(f(64), f(64)),
         "epsfill_fixup": lambda: ops.epsfill_fixup(torch.zeros(1, dtype=torch.int32), h(1, 4, 64), None, h(8, 64), None,

@@ -4,6 +4,8 @@ Integer codes / per-row integer terms are compared bit-exactly; floating outputs
 tolerance written next to each assert (fp16 output rounding is 2^-11 relative).
 """
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -11,6 +13,7 @@ import torch.nn.functional as F
 from oracle import fakequant as fq
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rel_l2(a, b):
@@ -672,6 +675,64 @@ def test_attn_cross_short_kv_register_kernel(ops, dev, B, Nq, H, lens):
     assert rel_l2(o.cpu().float(), o_gen.cpu().float()) < 1e-3
 
 
+def _cross_case(ops, dev, D, H, B, Nq, lens, varlen):
+    Cc = H * D
+    q = h16(B * Nq, Cc, seed=Nq + D).to(dev)
+    if varlen:
+        kv = h16(sum(lens), 2 * Cc, seed=2 + D).to(dev)
+        offs = [0]
+        for L in lens:
+            offs.append(offs[-1] + L)
+        off = torch.tensor(offs, dtype=torch.int32, device=dev)
+        kv_seq = 0
+    else:                                                  # fixed length: every sequence owns lens[0] rows
+        kv = h16(B * lens[0], 2 * Cc, seed=2 + D).to(dev)
+        offs = [b * lens[0] for b in range(B + 1)]
+        off, kv_seq = None, lens[0] * 2 * Cc
+    o = torch.full_like(q, float("nan"))
+    ops.attn_fwd(q, kv, kv[:, Cc:], o, B, Nq, max(lens), H, D, Nq * Cc, Cc, kv_seq, 2 * Cc, Nq * Cc, Cc, kv_off=off)
+    rows = torch.arange(0, Nq, max(1, Nq // 128))
+    qs = q.cpu().reshape(B, Nq, H, D)[:, rows]
+    outs = []
+    for b in range(B):
+        Lb = offs[b + 1] - offs[b]
+        kb = kv[offs[b]:offs[b] + Lb, :Cc].cpu().reshape(1, Lb, H, D)
+        vb = kv[offs[b]:offs[b] + Lb, Cc:].cpu().reshape(1, Lb, H, D)
+        outs.append(_attn_ref(qs[b:b + 1], kb, vb, D ** -0.5))
+    ref = torch.cat(outs).reshape(B * len(rows), Cc)
+    got = o.cpu().float().reshape(B, Nq, Cc)[:, rows].reshape(B * len(rows), Cc)
+    assert torch.isfinite(o).all()
+    return rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("D,H", [(16, 8), (32, 8), (64, 8), (72, 16)])
+@pytest.mark.parametrize("Lk", [1, 33, 64, 65, 128])
+def test_attn_cross_lds_kernel_every_head_dim(ops, dev, D, H, Lk):
+    """Round-4 advisor finding: attn_cross32_kernel (K / V resident in LDS) is dispatched for EVERY instantiated head dim
+    when Lk <= 128 and Lq >= 256, but only D = 72 was exercised.  Here D = 16 / 32 / 64 / 72 (their own NST / LD_REG
+    constants and LDS pad columns), key counts at every 32-key-half boundary, varlen (two sequences: the bound and a
+    ragged one) and fixed-length forms, Lq = 300 (ragged last query tile), against the fp32 softmax."""
+    assert _cross_case(ops, dev, D, H, 2, 300, [Lk, max(1, Lk - 7)], True) < 1e-3
+    assert _cross_case(ops, dev, D, H, 2, 300, [Lk], False) < 1e-3
+
+
+def test_attn_cross_register_kernel_still_covered():
+    """The round-1 register-resident cross kernel (attn_cross_reg_kernel) stays selectable (VQ_ATTN_CROSS=reg, read once
+    per process) and tested at Nq >= 256 - in a child process, since the default process binds the LDS kernel."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; import viditq_amd; "
+            "from viditq_amd import ops; import test_kernels_gpu as t; dev = torch.device('cuda:0'); "
+            "e = [t._cross_case(ops, dev, 72, 16, 1, 1000, [L], True) for L in (120, 80, 17, 128)]; "
+            "e.append(t._cross_case(ops, dev, 72, 16, 3, 300, [17, 120, 1], True)); print('ERRS', e); "
+            "assert max(e) < 1e-3" % (ROOT, os.path.join(ROOT, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VQ_ATTN_CROSS="reg"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "ERRS" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 @pytest.mark.parametrize("B,T,S,H,D", [(1, 16, 64, 16, 72), (2, 4, 9, 4, 16), (1, 16, 1024, 16, 72)])
 def test_attn_temporal(ops, dev, B, T, S, H, D):
     Cc = H * D
@@ -787,6 +848,34 @@ def test_gelu_rowquant_pair_shares_the_grid_over_the_batch(ops, dev, C, n_tok, s
     assert (qa.zx[:n_tok].cpu() + 128 - z.reshape(-1).int()).abs().max().item() <= 1
 
 
+@pytest.mark.parametrize("C,n_tok", [(4608, 300), (1152, 131)])
+def test_gelu_rowquant_pair_with_a_smoothing_vector_that_has_no_reciprocal(ops, dev, C, n_tok):
+    """Round-4 advisor finding: a smoothing vector with ONE channel outside vq_smooth_reciprocal's precondition (a
+    significand of all ones) has no reciprocal vector (ops.smooth_rcp -> None).  B = 1 then divides exactly; the B = 2
+    entry used to REFUSE (VQ_EUNSUP) - after the producing GEMM had already been launched with the plain epilogue.  Now the
+    pair takes the register kernel with the IEEE division: bit-identical to the explicit exact-division call, and - on a
+    clean copy of the vector - to the reciprocal form.  Also covers smoothed pair rows <= 1536 channels (no LDS kernel)."""
+    import struct
+    h = h16(2, n_tok, C, scale=2.0, seed=7 * C + n_tok).to(dev)
+    s_ok = (torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5).float()
+    s_bad = s_ok.clone()
+    s_bad[17] = struct.unpack("f", struct.pack("I", 0x3FFFFFFF))[0]            # 1.9999999: significand all ones
+    s_bad, s_ok = s_bad.to(dev), s_ok.to(dev)
+    assert ops.smooth_rcp(s_bad) is None and ops.smooth_rcp(s_ok) is not None
+    qa = ops.gelu_rowquant(h, s=s_bad)                                          # used to raise
+    qe = ops.gelu_rowquant(h, s=s_bad, fast_div=False)
+    for a, b in ((qa.xq, qe.xq), (qa.sx, qe.sx), (qa.zx, qe.zx), (qa.R, qe.R)):
+        assert torch.equal(a, b)
+    assert torch.equal(qa.sx[:n_tok], qa.sx[n_tok:]) and torch.equal(qa.zx[:n_tok], qa.zx[n_tok:])
+    act = torch.nn.functional.gelu(h.float(), approximate="tanh").half()
+    qb = ops.rowquant(act, s=s_bad)                                             # generic pair kernel, IEEE division
+    assert (qa.xq == qb.xq).float().mean().item() > 0.99 and (qa.xq.int() - qb.xq.int()).abs().max().item() <= 1
+    # a vector WITH a reciprocal: reciprocal form == exact division, bit for bit (Markstein), on both pair kernels
+    qf, qx = ops.gelu_rowquant(h, s=s_ok), ops.gelu_rowquant(h, s=s_ok, fast_div=False)
+    for a, b in ((qf.xq, qx.xq), (qf.sx, qx.sx), (qf.zx, qx.zx), (qf.R, qx.R)):
+        assert torch.equal(a, b)
+
+
 def test_gemm_i8_batched_equals_separate_launches(ops, dev):
     """vq_gemm_i8_batched: one activation, stacked weight sets (the kv_linear of every block on the same prompt
     tokens) - bit-identical to one vq_gemm_i8 launch per weight set."""
@@ -844,6 +933,68 @@ def test_gemm_full_size_against_the_library_integer_matmul(ops, dev, N, K, w_bit
     assert bool((diff <= ulp + slack).all())
     assert float((diff > 0).float().mean()) < 5e-2
     assert float((out.double() - exact).norm() / exact.norm()) < 3.2e-4
+
+
+def test_gemm_stamped_launch_equals_the_plain_one_and_reads_a_sane_clock(ops, dev):
+    """vq_gemm_i8_stamped (bench telemetry): same outputs as vq_gemm_i8 with the plain epilogue, ragged edges included, and
+    stamps that describe a kernel - ordered phase boundaries in every wave, a shader clock between 0.5 and 2.6 GHz."""
+    for M, N, K in ((1024, 1152, 1152), (300, 580, 256)):
+        x = h16(1, M, K, scale=1.5, seed=M).to(dev)
+        W = h16(N, K, scale=0.04, seed=N).to(dev)
+        b = h16(N, scale=0.1, seed=5).float().to(dev)
+        qa = ops.rowquant(x)
+        d, z = ops.weight_minmax(W, 8)
+        pw = ops.pack_weight(W, d, z, 8)
+        ref = ops.gemm_i8(qa, pw, bias=b, variant=11)
+        out, st = ops.gemm_i8_stamped(qa, pw, bias=b)
+        assert torch.equal(out, ref)
+        s = st.cpu()
+        assert s.shape == (((M + 255) // 256) * ((N + 287) // 288), 8, 10)
+        assert bool((s[:, :, 1:7] >= s[:, :, 0:6]).all()) and bool((s[:, :, 8] > s[:, :, 7]).all())
+        tel = ops.shader_clock_ghz(st)
+        assert 0.5 < tel["ghz"] < 2.6, tel
+        assert tel["phase_cycles"]["main_loop"] > 0
+
+
+@pytest.mark.parametrize("w_bits", [8, 4])
+def test_gemm_fp_dequant_under_adversarial_cancellation(ops, dev, w_bits):
+    """Round-4 advisor finding on the packed-fp32 epilogue (gemm_common.h ring_dequant<true>): y = (sx sw) acc + U P + V Q + b
+    rounds three products separately, so the error is a few fp32 ulps OF THE LARGEST TERM, not of the result.  Worst case
+    built on purpose: post-GELU rows (min -0.17, long positive tail: zero point near 0, centred codes near -128, |R| large),
+    all-positive weights (|cs| large), K = 4608 (|acc| beyond 2^24: float(acc) itself inexact).  The guaranteed bound -
+    per output one fp16 ulp + 4 x 2^-24 x the sum of the terms' magnitudes - is asserted against an int64 / fp64
+    evaluation, and the rel-L2 distance from the un-rounded result is recorded: the terms are ~10^3 x the result here and
+    the figure stays at the fp16 rounding's own (the fp32 error is 2^-24 x 10^3 = 6e-5 << 2^-11)."""
+    M, N, K = 2048, 1152, 4608
+    x = torch.nn.functional.gelu(h16(1, M, K, scale=3.0, seed=41).float(), approximate="tanh").half().to(dev)
+    W = (h16(N, K, scale=0.02, seed=43).float().abs() + 0.01).half().to(dev)
+    b = h16(N, scale=0.1, seed=5).float().to(dev)
+    qa = ops.rowquant(x)
+    d, z = ops.weight_minmax(W, w_bits)
+    pw = ops.pack_weight(W, d, z, w_bits)
+    out = ops.gemm_i8(qa, pw, bias=b).float()
+    if w_bits == 8:
+        ws = pw.wq
+    else:
+        g = pw.wq.view(N, pw.Kp // 8, 4).to(torch.int16)
+        ws = torch.cat([g & 15, g >> 4], dim=2).reshape(N, pw.Kp).to(torch.int8)
+    acc = torch._int_mm(qa.xq, ws.t().contiguous()).long()
+    t_w = pw.zw.long()[None, :] * qa.R.long()[:, None]
+    t_x = qa.zx.long()[:, None] * pw.cs.long()[None, :]
+    tt = acc - t_w - t_x
+    terms = acc.abs() + t_w.abs() + t_x.abs()
+    assert int(acc.abs().max()) > 2 ** 24                       # the case the finding names
+    ratio = float(terms.double().mean() / tt.abs().double().mean())
+    assert ratio > 20, ratio                                    # strong cancellation: terms >> result
+    S = qa.sx.double()[:, None] * pw.sw.double()[None, :]
+    exact = S * tt.double() + b.double()[None, :]
+    ref = exact.half().float()
+    diff = (out - ref).abs()
+    ulp = 2.0 ** -10 * ref.abs().clamp(min=2.0 ** -14)
+    slack = (4 * 2.0 ** -24 * (S * terms.double() + b.abs().double()[None, :])).float()
+    assert bool((diff <= ulp + slack).all())
+    rel = float((out.double() - exact).norm() / exact.norm())
+    assert rel < 4e-4, (rel, ratio)
 
 
 @pytest.mark.parametrize("w_bits", [8, 4])
@@ -951,3 +1102,27 @@ def test_fp_edge_linear_against_fp32(ops, dev, M, N, K, act_in, act_out):
     xs = h16(M, K + 8, scale=1.0, seed=3).to(dev)[:, :K]
     o2 = ops.linear_f16(xs.contiguous(), w, None).float().cpu()
     assert rel_l2(o2, F.linear(xs.float().cpu(), w.float().cpu())) < 4e-4
+
+
+def test_fp_edge_linear_keeps_the_module_path_for_autograd_and_hooks(ops, dev):
+    """Round-4 advisor finding: fp_edge_linear by-passed the module (detached weights, no __call__) whenever x was fp16 on
+    the GPU - autograd silently cut, forward hooks skipped.  The kernel route is taken only when nothing can observe the
+    difference: under no_grad (or with no tensor requiring grad) and on a module without forward hooks."""
+    import viditq_amd  # noqa: F401
+    from viditq_amd.t2v.stdit import fp_edge_linear
+    lin = torch.nn.Linear(64, 32).half().to(dev)
+    x = h16(8, 64, seed=3).to(dev)
+    with torch.no_grad():
+        assert fp_edge_linear(lin, x) is not None                      # inference: the HIP kernel
+    assert fp_edge_linear(lin, x) is None                              # grad mode + parameters that require grad: module path
+    for p in lin.parameters():
+        p.requires_grad_(False)
+    assert fp_edge_linear(lin, x) is not None                          # nothing requires grad: kernel again
+    assert fp_edge_linear(lin, x.clone().requires_grad_(True)) is None
+    seen = []
+    h = lin.register_forward_hook(lambda m, i, o: seen.append(1))
+    with torch.no_grad():
+        assert fp_edge_linear(lin, x) is None                          # a hook would not fire: module path
+    h.remove()
+    with torch.no_grad():
+        assert fp_edge_linear(lin, x) is not None

@@ -521,6 +521,44 @@ def test_stdit_full_size_block0_pins_the_oracle_on_the_reference():
     assert e < 2e-5 and e < 0.05 * ref16, (e, ref16)
 
 
+def test_stdit_full_size_full_depth_floor_is_measured_not_argued():
+    """Round 5 (asked by the round-4 review): the parity FLOOR at the headline configuration.  The fp32 oracle runs the
+    SAME full-size, 28-block forward the imported reference left in stdit_full_ref.npz (~100 s on 8 cores) and its distance
+    from the reference's fp32 mode is taken at blocks 0 / 13 / 27 and at the output: 3e-8, 2.3e-3, 3.3e-3, 3.4e-3 in the
+    authoring container (profiles/r05_parity_floor.json, written by tools/parity_floor.py which also covers the W4A8 and
+    PixArt-Sigma full-size vectors).  Two fp32 implementations of the same arithmetic, differing only in summation order,
+    are 3.3e-3 apart after 28 blocks: flipped 8-bit codes at rounding ties, amplified by the contractions behind them.
+    The HIP path's 4.6e-3 at block 27 is 1.4 x this floor (GPU test: <= 1.75 x), the reference's own fp16 mode 2.2 x.
+    Asserted here: block 0 pins the restatement (< 2e-5); deeper, the oracle stays below 0.6 x the reference's fp16-mode
+    drift AND the floor is what the committed record says (within a factor 2: another BLAS reorders other sums and flips
+    other codes, the level stays).  Cross attention in the fixture: xformers restated (oracle/ref_import.py:127-143)."""
+    import json
+    import os
+    from helpers import stdit_full_inputs
+    from viditq_amd.t2v import STDiT
+    g = load_npz("stdit_full_ref.npz")
+    seed = int(g["seed"])
+    sd = _seeded_sd("stdit", seed, depth=28, Cc=4096, L=120)
+    geo = STDiT(input_size=(16, 64, 64), depth=1, hidden_size=1152, num_heads=16, model_max_length=120, caption_channels=4096)
+    sd["pos_embed"], sd["pos_embed_temporal"] = geo.pos_embed.half().float(), geo.pos_embed_temporal.half().float()
+    x, y, mask, t = stdit_full_inputs(seed)
+    cfg = dict(T=16, S=1024, H=16, depth=28, patch=(1, 2, 2), in_ch=4, out_ch=8, input_size=(16, 64, 64))
+    with torch.no_grad():
+        out, blocks = sr.stdit_forward(sd, cfg, x, t, y, mask, sr.QSpec(w_bits=8), return_blocks=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r05_parity_floor.json")) as f:
+        rec = json.load(f)["records"]
+    got = {"stdit_full/block%d" % i: (rel_l2(blocks[i][:, ::256], g["block%d" % i]),
+                                       rel_l2(g["block%d_ref_fp16" % i], g["block%d" % i])) for i in (0, 13, 27)}
+    got["stdit_full/out"] = (rel_l2(out[:, :, :, ::2, ::2], g["out"]), rel_l2(g["out_ref_fp16"], g["out"]))
+    assert got["stdit_full/block0"][0] < 2e-5, got
+    for k in ("stdit_full/block13", "stdit_full/block27", "stdit_full/out"):
+        e, r16 = got[k]
+        assert e < 0.6 * r16, (k, got)
+        assert 0.5 * rec[k]["oracle_fp32_vs_ref_fp32"] < e < 2.0 * rec[k]["oracle_fp32_vs_ref_fp32"], (k, e, rec[k])
+        assert abs(rec[k]["ref_fp16_vs_ref_fp32"] - r16) < 1e-6 * r16 + 1e-9      # same golden file as the record
+
+
 ATTN_KAT_CASES = [("L1024", 2, 1024, 16), ("L160", 3, 160, 4), ("L16", 64, 16, 8)]   # as tests/golden/make_golden.py
 
 

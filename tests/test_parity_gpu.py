@@ -65,12 +65,43 @@ def _stdit(gold, dev, wq, aq, cfg_split, fp=FP_LAYERS):
     return qnn
 
 
+_FLOOR = {}
+
+
+def parity_floor(name):
+    """The MEASURED floor at a full-size checkpoint: rel-L2 of the fp32 oracle from the reference's fp32 mode on the same
+    forward (tools/parity_floor.py -> profiles/r05_parity_floor.json, CPU, committed) - what two fp32 implementations of
+    the same arithmetic are apart there.  None for places without a measurement."""
+    if not _FLOOR:
+        import json
+        import os
+        f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_parity_floor.json")
+        _FLOOR["_"] = None
+        if os.path.exists(f):
+            with open(f) as fh:
+                _FLOOR.update({k: v["oracle_fp32_vs_ref_fp32"] for k, v in json.load(fh)["records"].items()})
+    return _FLOOR.get(name)
+
+
+def within_floor_bound(ent):
+    """DESIGN section 2 as restated in round 5: the HIP path is within max(1.25e-3, 1.75 x the measured fp32-vs-fp32 floor)
+    of the reference's fp32 mode (1.25e-3 = north_star's 1e-3 + the fp16 storage of one block's output; beyond depth ~2
+    the floor term takes over)."""
+    fl = ent.get("floor_fp32_oracle_vs_ref_fp32")
+    return fl is None or ent["vs_ref_fp32"] < max(1.25e-3, 1.75 * fl)
+
+
 def _rec(parity, name, got, ref32, ref16=None, **extra):
-    """achieved rel-L2 vs the reference's fp32 output, vs its fp16-mode output, and the reference's own fp16 deviation"""
+    """achieved rel-L2 vs the reference's fp32 output, vs its fp16-mode output, and the reference's own fp16 deviation
+    (+ the measured fp32-vs-fp32 floor of the place, where tools/parity_floor.py recorded one)"""
     ent = {"vs_ref_fp32": rel_l2(got, ref32)}
     if ref16 is not None:
         ent["vs_ref_fp16"] = rel_l2(got, ref16)
         ent["ref_fp16_vs_ref_fp32"] = rel_l2(ref16, ref32)
+    fl = parity_floor(name)
+    if fl is not None:
+        ent["floor_fp32_oracle_vs_ref_fp32"] = fl
+        ent["over_floor"] = ent["vs_ref_fp32"] / fl if fl > 0 else None
     ent.update(extra)
     parity[name] = ent
     return ent

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vq_gemm_i8_grouped": (_i, [_i] + [_vp] * 10 + [_i] * 6 + [_vp]),
     "vq_gemm_i8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp,
                         _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "vq_gemm_i8_stamped": (_i, [_vp] * 10 + [_i] * 5 + [_vp, _l, _vp]),
     "vq_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _l, _vp, _f, _vp]),
     "vq_attn_temporal": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _l, _f, _vp]),
     "vq_attn_temporal_rowquant": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _l, _i, _f,

@@ -7,11 +7,11 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libviditq_hip.so")
-SOURCES = ["api.hip", "rowquant.hip", "rowquant_fast.hip", "pack.hip", "gemm_i8.hip", "attention.hip", "sampler.hip", "fp_linear.hip"]
+SOURCES = ["api.hip", "rowquant.hip", "rowquant_fast.hip", "pack.hip", "gemm_i8.hip", "attention.hip", "sampler.hip", "fp_linear.hip", "clock_probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # sources whose MFMA accumulators stay in VGPRs: the AGPR form costs a v_accvgpr_read/write per softmax /
 # epilogue operand (attention).  VQ_VGPR_FORM="a.hip,b.hip" overrides the set for experiments.
-VGPR_FORM = {"attention.hip", "gemm_i8.hip"}
+VGPR_FORM = {"attention.hip", "gemm_i8.hip", "clock_probe.hip"}
 
 
 def _flags(src: str):

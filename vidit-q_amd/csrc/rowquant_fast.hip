@@ -1155,17 +1155,19 @@ bool vq_gelu_rowquant_fast(const half_t* x, const float* s, const float* s_rcp, 
 bool vq_gelu_rowquant_pair_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
                                 int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
     if (C > 4608 || Kp > 4608 || n_tok < 1) return false;
-    if (s)
-        return s_rcp && C > 1536 && n_tok >= 2 &&
-               launch_rq_smooth_lds<true, true>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st);
+    if (s && s_rcp && C > 1536 && n_tok >= 2 &&
+        launch_rq_smooth_lds<true, true>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st))
+        return true;
+    // every other smoothed case - a vector without a usable reciprocal (vq_smooth_reciprocal flagged a channel, or an
+    // unseen vector under graph capture: s_rcp == nullptr -> IEEE division, as B = 1 falls back), short rows - takes the
+    // register kernel with the smoothing operands from global memory, like the un-smoothed pair
     dim3 grid((n_tok + RQF_WAVES / 2 - 1) / (RQF_WAVES / 2)), block(RQF_THREADS);
-#define RQGP_GO(M_)                                                                                                  \
-    hipLaunchKernelGGL((rowquant_fast_kernel<M_, false, false, true, true>), grid, block, 0, st, x, (const half_t*)nullptr, \
-                       1, (const float*)nullptr, (const float*)nullptr, xq, sx, zx, R, (float*)nullptr, n_tok, C, Kp, n_bits, \
-                       status)
-    if (Kp <= 512) RQGP_GO(1);
-    else if (Kp <= 1536) RQGP_GO(3);
-    else RQGP_GO(9);
+#define RQGP_GO(M_, S_)                                                                                              \
+    hipLaunchKernelGGL((rowquant_fast_kernel<M_, S_, false, true, true>), grid, block, 0, st, x, (const half_t*)nullptr, \
+                       1, s, s_rcp, xq, sx, zx, R, (float*)nullptr, n_tok, C, Kp, n_bits, status)
+    if (Kp <= 512) { if (s) RQGP_GO(1, true); else RQGP_GO(1, false); }
+    else if (Kp <= 1536) { if (s) RQGP_GO(3, true); else RQGP_GO(3, false); }
+    else { if (s) RQGP_GO(9, true); else RQGP_GO(9, false); }
 #undef RQGP_GO
     return true;
 }

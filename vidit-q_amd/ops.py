@@ -394,6 +394,38 @@ def gemm_i8(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None, out: 
     return out
 
 
+def gemm_i8_stamped(a: QAct, w: PackedWeight, bias: Optional[torch.Tensor] = None):
+    """Diagnostics: ONE launch of the default 8-bit GEMM (256 x 288 tile, plain epilogue) with per-wave stamps.
+    -> (out [M, N] fp16, stamps [tiles, 8, 10] int64: 0-6 shader cycles per phase boundary, 7 / 8 the chip's 100 MHz wall
+    clock at entry / exit).  `shader_clock_ghz(stamps)` turns them into the clock the kernel ran at."""
+    if a.K != w.K or a.Kp != w.Kp or w.n_bits != 8:
+        raise VQError("gemm_i8_stamped: 8-bit weights of the activation's K")
+    M, N = a.rows, w.N
+    if not a.xq.is_cuda:
+        raise VQError("gemm_i8_stamped needs GPU tensors")
+    out = torch.empty((M, N), dtype=torch.float16, device=a.xq.device)
+    tiles = ((M + 255) // 256) * ((N + 287) // 288)
+    stamps = torch.zeros((tiles, 8, 10), dtype=torch.int64, device=a.xq.device)
+    check(_L().vq_gemm_i8_stamped(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs), _p(bias),
+                                  _p(out), out.stride(0), M, N, a.K, a.Kp, _p(stamps), stamps.numel(), _stream()),
+          "vq_gemm_i8_stamped")
+    return out, stamps
+
+
+def shader_clock_ghz(stamps: torch.Tensor) -> dict:
+    """Median over waves of (shader cycles) / (10 ns wall-clock ticks) of a stamped GEMM launch, plus the tile phases in
+    shader cycles (means over waves): what bench.py records beside its rates."""
+    s = stamps.detach().cpu().double()
+    cyc = s[:, :, 6] - s[:, :, 0]
+    ticks = (s[:, :, 8] - s[:, :, 7]).clamp(min=1)
+    ghz = float((cyc / ticks).median()) / 10.0
+    ph = (s[:, :, 1:7] - s[:, :, 0:6]).mean(dim=(0, 1))
+    names = ["prologue", "main_loop", "barrier_params", "dequant_slab", "store_issue", "store_drain"]
+    span_us = float(s[:, :, 8].max() - s[:, :, 7].min()) / 100.0
+    return {"ghz": ghz, "tile_cycles": float(cyc.mean()), "launch_span_us": span_us,
+            "phase_cycles": {n: float(v) for n, v in zip(names, ph)}}
+
+
 # --------------------------------------------------------------------------- attention
 @dataclass
 class PackedStack:

@@ -286,7 +286,10 @@ class QuantLayer(nn.Module):
         picks that GEMM's epilogue)."""
         if not isinstance(self.act_quantizer, DynamicActQuantizer):
             return False
-        return B == 1 or (B == 2 and (s is None or K > 1536))
+        # B = 2 with a smoothing vector: the LDS-staged pair kernel when the vector has a usable reciprocal and the row is
+        # long, else the register pair kernel (exact division when ops.smooth_rcp(s) is None) - never a refusal after the
+        # producing GEMM was launched with the plain epilogue
+        return B in (1, 2)
 
     def quantize_gelu_input(self, h3: torch.Tensor, s: Optional[torch.Tensor]) -> Optional[ops.QAct]:
         """act(GELU tanh) + this layer's activation quantizer in one pass over the PRE-activation ``h3`` [B, n, K], B = 1

@@ -84,6 +84,12 @@ def fp_edge_linear(layer, x, act_in=0, act_out=0):
         w, b = layer.org_weight, layer.org_bias
     if w.dtype != torch.float16 or w.numel() == 0 or w.shape[1] % 8 or w.shape[0] % 4 or (b is not None and b.dtype != torch.float16):
         return None
+    # the kernel is forward-only and by-passes the module's __call__: anything autograd or a hook would observe keeps the
+    # module path (round-4 advisor finding: the graph was silently cut and forward hooks skipped)
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        return None
+    if getattr(layer, "_forward_hooks", None) or getattr(layer, "_forward_pre_hooks", None):
+        return None
     # the edge kernel is built for SKINNY problems (one 16 x 16 output tile per workgroup, no operand reuse): few rows, few
     # columns or a short contraction.  A full-size FP Linear (16384 x 4608 x 1152: the block MLP of an FP calibration
     # pass) stays with the vendor GEMM - it is not part of the quantized hot path.
