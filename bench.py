@@ -30,8 +30,8 @@ PEAK_HBM = 8.0e12
 MP_SAMPLING = 20          # the mixed-precision plan's schedule: ONE constant for the widths that travel in the broadcast
                           # (stdit_legs) and the config applied per step range (_measure_plan) - they must name the same layers
 EXTRA_STEPS, EXTRA_WARMUP = 10, 3     # timed steps / warm-ups of the `extras` legs (4 / 2 until round 4: too short to be stable)
-GEMM_KERNEL = ("gemm_i8_wide_kernel<256,288,4,2,EPI,stagger> (W8A8 Linear: int8 MFMA 16x16x64, full-line LDS-DMA double "
-               "buffer, fused dequant epilogue)")
+GEMM_KERNEL = ("gemm_i8_wide_kernel<256,288,4,2,EPI,stagger,W4,0,INT=1> (W8A8 Linear: int8 MFMA 16x16x64, full-line LDS-DMA double "
+               "buffer, interior form: scalar-addressed stage pieces issued by one wave per SIMD, fused dequant epilogue)")
 
 
 
@@ -40,8 +40,19 @@ GEMM_KERNEL = ("gemm_i8_wide_kernel<256,288,4,2,EPI,stagger> (W8A8 Linear: int8 
 # Every leg therefore records what the part was doing: board power, shader clock and temperature before / during / after
 # (amdgpu sysfs hwmon where the container exposes it, `rocm-smi --json` otherwise), and the clock the GEMM itself ran at
 # (one stamped launch behind a back-to-back burst: shader cycle counter against the chip's 100 MHz wall clock).
+def _pci_bus_id(index):
+    """'0000:05:00.0' of HIP device `index` (torch's device properties; None when the build does not expose them)"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        return "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def _sysfs_gpu(index):
-    """hwmon files of the index-th amdgpu device, or None"""
+    """hwmon files of the amdgpu card that IS HIP device `index`: matched by PCI bus id (a GPU box shows every card of the
+    node in /sys/class/drm, the process owns one of them); else the only card whose render node exists in /dev/dri; else None
+    (rocm-smi is used instead) - never a guess."""
     import glob
     cards = []
     for dev_dir in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
@@ -52,10 +63,16 @@ def _sysfs_gpu(index):
             continue
         hw = sorted(glob.glob(os.path.join(dev_dir, "hwmon", "hwmon*")))
         if hw:
-            cards.append((dev_dir, hw[0]))
-    if not cards:
+            cards.append((os.path.basename(os.path.realpath(dev_dir)), dev_dir, hw[0]))
+    bus = _pci_bus_id(index)
+    pick = [c for c in cards if bus and c[0].lower() == bus.lower()]
+    if not pick:
+        mine = [c for c in cards if any(os.path.exists(os.path.join("/dev/dri", os.path.basename(r)))
+                                        for r in glob.glob(os.path.join(c[1], "drm", "renderD*")))]
+        pick = mine if len(mine) == 1 else []
+    if not pick:
         return None
-    dev_dir, hw = cards[index % len(cards)]
+    _, dev_dir, hw = pick[0]
     f = {}
     for key, names in (("power_w", ("power1_average", "power1_input")), ("sclk_mhz", ("freq1_input",)),
                        ("mclk_mhz", ("freq2_input",)), ("temp_c", ("temp2_input", "temp1_input"))):
@@ -63,12 +80,16 @@ def _sysfs_gpu(index):
             if os.path.exists(os.path.join(hw, n)):
                 f[key] = os.path.join(hw, n)
                 break
+    if f:
+        f["_card"] = os.path.basename(os.path.dirname(dev_dir)) + " @ " + pick[0][0]
     return f or None
 
 
 def _read_sysfs(files):
     out = {}
     for k, path in files.items():
+        if k.startswith("_"):
+            continue
         try:
             v = float(open(path).read().strip())
         except (OSError, ValueError):
@@ -115,7 +136,7 @@ class Telemetry:
     def __init__(self, index):
         self.index = index
         self.files = _sysfs_gpu(index)
-        self.source = "sysfs hwmon" if self.files else "rocm-smi"
+        self.source = ("sysfs hwmon of %s" % self.files["_card"]) if self.files else "rocm-smi"
         self._stop = None
         self._rows = []
 
@@ -123,9 +144,14 @@ class Telemetry:
         return _read_sysfs(self.files) if self.files else _rocm_smi(self.index)
 
     def start(self):
-        if not self.files:
-            return
         import threading
+        if not self.files:
+            # no sysfs sensor for this device: ONE rocm-smi reading taken while the timed region runs (the process start
+            # of rocm-smi, ~0.3-0.6 s, puts the reading inside a region of >= 10 steps; the loop is GPU-bound)
+            self._one = {}
+            self._th = threading.Thread(target=lambda: self._one.update(_rocm_smi(self.index)), daemon=True)
+            self._th.start()
+            return
         self._rows = []
         self._stop = threading.Event()
 
@@ -137,6 +163,12 @@ class Telemetry:
         self._th.start()
 
     def stop(self):
+        if not self.files:
+            if getattr(self, "_th", None) is None:
+                return None
+            self._th.join(timeout=30)
+            self._th = None
+            return dict(self._one, samples=1, how="one rocm-smi reading started with the timed region")
         if self._stop is None:
             return None
         self._stop.set()
@@ -156,7 +188,7 @@ _CLOCK_PROBE = {}
 TEL = None          # Telemetry of this rank's device, set in main()
 
 
-def gemm_clock_probe(dev, burst=24):
+def gemm_clock_probe(dev, burst=24, reps=7):
     """The shader clock UNDER the GEMM on this box, now: `burst` back-to-back launches of the qkv shape (16384 x 3456 x
     1152, ~75 us each), then one stamped launch of the same problem (ops.gemm_i8_stamped)."""
     from viditq_amd import ops
@@ -169,15 +201,20 @@ def gemm_clock_probe(dev, burst=24):
                             out=torch.empty((16384, 3456), dtype=torch.float16, device=dev))
     qa, pw, out = _CLOCK_PROBE["qa"], _CLOCK_PROBE["pw"], _CLOCK_PROBE["out"]
     try:
-        for _ in range(burst):
-            ops.gemm_i8(qa, pw, out=out, variant=11)
-        _, st = ops.gemm_i8_stamped(qa, pw)
+        ts = []
+        for _ in range(reps):
+            for _ in range(burst):
+                ops.gemm_i8(qa, pw, out=out, variant=11)
+            ts.append(ops.gemm_i8_stamped(qa, pw)[1])
         torch.cuda.synchronize()
-        t = ops.shader_clock_ghz(st)
-        return {"ghz": round(t["ghz"], 3), "tile_cycles": round(t["tile_cycles"]), "launch_span_us": round(t["launch_span_us"], 1),
-                "phase_cycles": {k: round(v) for k, v in t["phase_cycles"].items()},
-                "how": "%d back-to-back qkv-shape launches, then one stamped launch: shader cycle counter / 100 MHz wall clock, "
-                       "median over the 6144 waves" % burst}
+        t = sorted((ops.shader_clock_ghz(st) for st in ts), key=lambda d: d["ghz"])
+        med = t[len(t) // 2]
+        return {"ghz": round(med["ghz"], 3), "ghz_min": round(t[0]["ghz"], 3), "ghz_max": round(t[-1]["ghz"], 3),
+                "tile_cycles": round(med["tile_cycles"]), "launch_span_us": round(med["launch_span_us"], 1),
+                "phase_cycles": {k: round(v) for k, v in med["phase_cycles"].items()},
+                "how": "%d x (%d back-to-back qkv-shape launches, then one stamped launch of the same problem): shader cycle counter "
+                       "/ 100 MHz wall clock, median over the 6144 waves of a launch; median / min / max over the %d stamped launches"
+                       % (reps, burst, reps)}
     except Exception as e:  # noqa: BLE001  (telemetry must never lose the line)
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -16,9 +16,16 @@ extern "C" int vq_gemm_i8_stamped(const int8_t* xq, const float* sx, const int32
     if (n_stamps < tiles * 8 * 10) return VQ_ESHAPE;
     GemmArgs a{xq, sx, zx, R, (const uint8_t*)wq, sw, zw, cs, bias, (half_t*)out, nullptr,
                reinterpret_cast<const float*>(stamps), ldo, 1, M, N, K, Kp, VQ_EPI_NONE, 0};
-    constexpr size_t LDS = 2 * ((size_t)256 * 128 + (size_t)288 * 128);
-    auto k = gemm_i8_wide_kernel<256, 288, 4, 2, VQ_EPI_NONE, true, false, 16>;
-    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    // ring (2 x 68 KiB) or the epilogue's eight 64 x 288 slabs + parameter blocks, whichever is larger (launch_gemm_wide_e)
+    constexpr size_t RING = 2 * ((size_t)256 * 128 + (size_t)288 * 128);
+    constexpr size_t EPIL = (size_t)8 * 64 * (144 * 2 + 16) + 4 * 288 * 4 + 12 * 256;
+    constexpr size_t LDS = RING > EPIL ? RING : EPIL;
+    static_assert(LDS <= 163840, "LDS budget of one CU");
+    // the form the library itself would pick for this shape: interior (gemm_wide.h INT 1) or general
+    const bool interior = M % 256 == 0 && N % 288 == 0;
+    auto k = interior ? gemm_i8_wide_kernel<256, 288, 4, 2, VQ_EPI_NONE, true, false, 16, 1>
+                      : gemm_i8_wide_kernel<256, 288, 4, 2, VQ_EPI_NONE, true, false, 16, 0>;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     if (e != hipSuccess) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;

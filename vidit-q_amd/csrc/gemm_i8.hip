@@ -55,10 +55,25 @@ static bool vq_use_12w(const GemmArgs& a, int sets) {
     if (mode == 2) return tiles > 256 || a.Kp >= 4608;
     return a.N >= 4608 || a.Kp >= 4608;
 }
+// Launches made of interior tiles only (M % tile height == 0, N % 288 == 0) take the scalar-addressed form of the same
+// kernel with asymmetric DMA issue (gemm_wide.h, INT 1: waves 0-3 issue every stage piece): `variant` 19, and the library's
+// own choice for such shapes - every Linear of the benchmarked STDiT / PixArt-Sigma configurations.  Bit-identical to the
+// general form (tested).  VQ_GEMM_INT = 0 keeps the general form everywhere, 2 selects the measurement arm (scalar
+// addressing, every wave issuing) - A/B runs on one box.
+static int vq_int_mode() {
+    static const int mode = getenv("VQ_GEMM_INT") ? atoi(getenv("VQ_GEMM_INT")) : 1;
+    return mode;
+}
 template <bool W4>
 static int launch_gemm_auto(const GemmArgs& a, hipStream_t st, int variant) {
     const int sets = a.nbatch > 1 ? a.nbatch : a.ngroups > 1 ? a.ngroups : 1;
     const bool half = variant == 16 || (variant == VQ_GEMM_DEFAULT && vq_half_tiles(a.M, a.N, sets));
+    const int bm = half ? 128 : 256;
+    const bool interior = a.M % bm == 0 && a.N % 288 == 0;
+    const int im = variant == 19 ? 1 : (variant == VQ_GEMM_DEFAULT && interior) ? vq_int_mode() : 0;
+    if (variant == 19 && !interior) return VQ_ESHAPE;
+    if (im == 1) return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 1>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 1>(a, st);
+    if (im == 2) return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 2>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 2>(a, st);
     if (half) return launch_gemm_wide<128, 288, 4, 2, true, W4>(a, st);
     if (variant == 18 || (variant == VQ_GEMM_DEFAULT && vq_use_12w(a, sets))) {
         if (a.M % 256 != 0 || a.N % 288 != 0 || (a.N & 7) != 0 || (a.ldo & 7) != 0 ||
@@ -91,6 +106,7 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         case 11:               // 256 x 288 tile: full-line double buffer, 128 bytes of k per row and stage, staggered DMA issue
         case 16:               // 128 x 288 tile of the same kernel
         case 18:               // 256 x 288 tile, twelve waves of 64 x 96 (interior tiles only: VQ_ESHAPE otherwise)
+        case 19:               // 256 x 288 tile, interior form: scalar-addressed pieces, waves 0-3 issue (VQ_ESHAPE unless M % 256 == 0, N % 288 == 0)
             if (w_bits <= 4) return launch_gemm_auto<true>(a, st, variant);
             return launch_gemm_auto<false>(a, st, variant);
         default:

@@ -22,17 +22,29 @@
 // LDS rows are 128 B with the 16-byte chunk index XOR-ed by (row >> 1) & 7 (W4: 64 B rows, (row >> 2) & 3).
 // ---------------------------------------------------------------------------
 // ABL (profiling only, results wrong): 1 no DMA after the prologue, 2 no MFMA, 4 no barrier, 8 no fragment reads
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>
+//
+// INT (round 5): launches made of INTERIOR tiles only (M % BM == 0, N % BN == 0; the launcher checks).  Without edge rows
+// nothing needs clamping, so a stage piece is addressed as ONE lane offset per wave (row lane >> 3 of the piece, swizzled
+// 16-byte chunk; it depends on the piece only through its parity, and with an even number of issuing waves all pieces of a
+// wave share one parity) + a SCALAR row / k offset in the buffer instruction's soffset - 2 VGPRs instead of 9 - and
+//   INT 1: waves 0 .. NW/2-1 (one per SIMD) issue EVERY piece of a stage right behind the stage barrier, their SIMD partners
+//          none ("asymmetric issue": the closest a 240-register kernel gets to a loader role, profiles/r05_gemm_loader.md);
+//   INT 2: every wave issues its share, staggered as in the general form (measurement arm: addressing alone).
+// Same stages, fragment reads, MFMA order and epilogue: bit-identical results (tested); back to back 2-4 % faster on the
+// single-round launches and 14 % on fc1 / fc2 (main loop 1479 -> 1399 cycles per k-step, prologue 5.1 k -> 4.0 k cycles).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0, int INT = 0>
 __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, const int tid_) {
     constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int NI = INT == 1 ? NW / 2 : NW;        // issuing waves
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int WROW = W4 ? 64 : 128;               // bytes per weight row and stage
     constexpr int XP = BM / 8, WP = BN * WROW / 1024; // 1 KiB DMA pieces
     constexpr int STAGE = BM * 128 + BN * WROW;
     constexpr int PIECES = XP + WP;
-    constexpr int PPW = (PIECES + NW - 1) / NW;
-    constexpr int PLAST = PIECES - (PPW - 1) * NW;
+    constexpr int PPW = (PIECES + NI - 1) / NI;
+    constexpr int PLAST = PIECES - (PPW - 1) * NI;
+    static_assert(INT == 0 || (NI % 2 == 0 && XP % 2 == 0), "one piece parity per issuing wave");
     constexpr int BARJ = TN - 2;                      // after the last fragment read of the current stage
     constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (next tile)
     static_assert((TM == 8 || TM == 4 || TM == 2) && TN >= 3 && TN % 3 == 0, "fragment rings below");
@@ -89,12 +101,19 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const bool full_wave = (PIECES % NW == 0) || wave < PLAST;
-    const bool late = STAGGER && wave >= NW / 2;      // wave-uniform
+    const bool full_wave = (PIECES % NI == 0) || wave < PLAST;
+    const bool issuer = wave < NI;                    // wave-uniform (INT 1: one wave per SIMD)
+    const bool late = INT != 1 && STAGGER && wave >= NW / 2;      // wave-uniform
 
-    uint32_t soff[PPW];
+    uint32_t soff[INT ? 2 : PPW];
+    if constexpr (INT != 0) {
+        // [0]: token rows (128-byte stage rows), [1]: weight rows (W4: 64-byte rows, 16 per piece - its swizzle phase
+        // (row >> 2) & 3 = (lane >> 4) & 3 does not depend on the piece at all)
+        soff[0] = (uint32_t)(lane >> 3) * (uint32_t)a.Kp + (uint32_t)(((lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7)) * 16);
+        soff[1] = W4 ? (uint32_t)(lane >> 2) * (uint32_t)(a.Kp >> 1) + (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16) : soff[0];
+    }
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
+    for (int i = 0; i < (INT ? 0 : PPW); ++i) {
         const int p = wave + i * NW;
         if (p < XP) {
             const int r = p * 8 + (lane >> 3);
@@ -129,8 +148,28 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     const int4v rs_x = mk_rsrc(a.xq), rs_w = mk_rsrc(a.wq);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem);
     auto issue = [&](int stage, int kt) {
+        if constexpr (INT != 0) {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
+            for (int i = 0; i < PPW; ++i) {
+                const int p = wave + i * NI;
+                if (PIECES % NI == 0 || p < PIECES) {
+                    const unsigned dst = lds0 + stage * STAGE + p * 1024;
+                    if (p < XP) {
+                        const unsigned so = (unsigned)(m0 + p * 8) * (unsigned)a.Kp + kt * 128;
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[0]), "s"(rs_x), "s"(so)
+                                     : "memory", "m0");
+                    } else {
+                        const unsigned so = W4 ? (unsigned)(n0 + (p - XP) * 16) * (unsigned)(a.Kp >> 1) + kt * 64
+                                               : (unsigned)(n0 + (p - XP) * 8) * (unsigned)a.Kp + kt * 128;
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(soff[1]), "s"(rs_w), "s"(so)
+                                     : "memory", "m0");
+                    }
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < (INT ? 0 : PPW); ++i) {
             const int p = wave + i * NW;
             if (PIECES % NW == 0 || p < PIECES) {
                 const unsigned dst = lds0 + stage * STAGE + p * 1024;
@@ -177,13 +216,15 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     };
 
     const int nkt = a.Kp / 128;
-    issue(0, 0);
-    if (nkt > 1) {
-        issue(1, 1);
-        if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (INT != 1 || issuer) {
+        issue(0, 0);
+        if (nkt > 1) {
+            issue(1, 1);
+            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __builtin_amdgcn_s_barrier();
     if (ts) ts[1] = __builtin_readcyclecounter();
@@ -201,7 +242,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
                 __builtin_amdgcn_sched_barrier(0);                                                         \
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
                 if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                              \
-                if (!(ABL & 1) && !late && kt + 2 < nkt) issue(cur, kt + 2);                                             \
+                if (!(ABL & 1) && !late && (INT != 1 || issuer) && kt + 2 < nkt) issue(cur, kt + 2);                     \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
             }                                                                                              \
             if (!(ABL & 1) && H == 0 && j == DMA_B && late && kt >= 1 && more) {                                         \
@@ -261,12 +302,12 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI, 16, VQ_GEMM_FP_DEQUANT, SROWS>(a, smem, acc, m0, n0, ts, tid, gate_row != nullptr);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0, int INT = 0>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(GemmArgs a) {
-    gemm_i8_wide_tile<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4, ABL>(a, blockIdx.x, threadIdx.x);
+    gemm_i8_wide_tile<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4, ABL, INT>(a, blockIdx.x, threadIdx.x);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int INT = 0>
 static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
@@ -276,7 +317,8 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
     const int tiles = MT * NTl * (a.nbatch > 1 ? a.nbatch : a.ngroups > 1 ? a.ngroups : 1);
-    auto k = gemm_i8_wide_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4>;
+    if (INT != 0 && (a.M % BM != 0 || a.N % BN != 0)) return VQ_ESHAPE;      // interior tiles only
+    auto k = gemm_i8_wide_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4, 0, INT>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
     if (e != hipSuccess) {
@@ -287,13 +329,13 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     return vq_check_launch();
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STAGGER, bool W4 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STAGGER, bool W4 = false, int INT = 0>
 static int launch_gemm_wide(const GemmArgs& a, hipStream_t st) {
     switch (a.epilogue) {
-        case VQ_EPI_NONE: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, STAGGER, W4>(a, st);
-        case VQ_EPI_GELU: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, STAGGER, W4>(a, st);
+        case VQ_EPI_NONE: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_NONE, STAGGER, W4, INT>(a, st);
+        case VQ_EPI_GELU: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GELU, STAGGER, W4, INT>(a, st);
         case VQ_EPI_GATE_RESID:
-            return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, STAGGER, W4>(a, st);
-        default: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, STAGGER, W4>(a, st);
+            return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_GATE_RESID, STAGGER, W4, INT>(a, st);
+        default: return launch_gemm_wide_e<BM, BN, WAVES_M, WAVES_N, VQ_EPI_RESID, STAGGER, W4, INT>(a, st);
     }
 }

@@ -44,6 +44,20 @@ __device__ __forceinline__ void rq_gelu_tanh8(half8& h) {
 }
 
 
+__device__ __forceinline__ void rq_gelu_tanh4(half4& h) {      // the same expression on four values (the 8-byte tail of a split row)
+    const float2v c1 = {-0.044715f * 2.302208198f, -0.044715f * 2.302208198f}, c2 = {-2.302208198f, -2.302208198f};
+    const float2v one = {1.0f, 1.0f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float2v x = {(float)h[2 * j], (float)h[2 * j + 1]};
+        const float2v w = x * __builtin_elementwise_fma(x * x, c1, c2);
+        const float2v d = float2v{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + one;
+        const float2v g = x * float2v{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        h[2 * j] = (half_t)g[0];
+        h[2 * j + 1] = (half_t)g[1];
+    }
+}
+
 // quantize 8 values -> two packed dwords of (code - cx); returns sum of raw codes
 template <bool SAT8>
 __device__ __forceinline__ uint32_t rq_quant8_t(const float (&v)[8], float inv, float delta, float zp, float qmax,
@@ -225,6 +239,105 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
         zx[tok] = izx;
         R[tok] = rs - C * izx;
         if (zpf) zpf[tok] = zp;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LONG rows split over TWO partner waves (round 5; C = 4608: the fc2 input behind GELU, 59 us per launch = the largest
+// HBM-bound kernel of a block).  rowquant_fast_kernel<9> gives a wave a whole 4608-channel row: 72 elements per lane, 1205
+// VALU instructions (144 of them transcendental) between its loads and its stores, 16384 waves = 2.3 generations of resident
+// waves that load, compute and store in step - 39 us of VALU issue and ~40 us of HBM time that overlap only partly
+// (profiles/r04_hbm_kernels_pmc.md: WAIT_ANY 0.35-0.66, fabric bytes exactly algorithmic).  Here waves 2k / 2k + 1 of a
+// workgroup take the two HALVES of a row - 36 elements per lane, the per-lane work of the C = 1152 half-wave kernels, the
+// fastest quantizers of the step - and exchange min / max and the code sums through LDS: half the instruction stream per
+// wave, half the registers (8 resident waves per SIMD), twice the wave generations, so loads, arithmetic and stores of
+// different waves interleave instead of alternating chip-wide.  Same per-element expressions as rowquant_fast_kernel
+// (rq_gelu_tanh8, packed fp16 min / max, vq_row_grid, rq_round_group): bit-identical outputs (tested).
+// C / 2 = NF * 512 + (TAIL8 ? 256 : 0) channels per wave: NF 16-byte loads per lane + one 8-byte load.
+// ---------------------------------------------------------------------------
+template <int NF, bool TAIL8, bool GELU>
+__global__ __launch_bounds__(RQF_THREADS) void rowquant_split_kernel(const half_t* __restrict__ x, int8_t* __restrict__ xq,
+                                                                     float* __restrict__ sx, int32_t* __restrict__ zx,
+                                                                     int32_t* __restrict__ R, int n_tok, int n_bits,
+                                                                     int32_t* status) {
+    constexpr int HC = NF * 512 + (TAIL8 ? 256 : 0), C = 2 * HC;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = wv & 1;
+    int tok = blockIdx.x * (RQF_WAVES / 2) + (wv >> 1);
+    const bool live = tok < n_tok;
+    if (!live) tok = n_tok - 1;                        // stays for the workgroup barriers, writes nothing
+    const float qmax = (float)((1 << n_bits) - 1);
+    const int cx = (n_bits == 8) ? 128 : 0;
+    const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
+    const half_t* row = x + (size_t)tok * C + half * HC;
+
+    half8 h[NF];
+    half4 ht;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) h[i] = *reinterpret_cast<const half8*>(row + lane * 8 + i * 512);
+    if constexpr (TAIL8) ht = *reinterpret_cast<const half4*>(row + NF * 512 + lane * 4);
+    half8 mn, mx;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        if constexpr (GELU) rq_gelu_tanh8(h[i]);
+        mn = i == 0 ? h[0] : __builtin_elementwise_min(mn, h[i]);
+        mx = i == 0 ? h[0] : __builtin_elementwise_max(mx, h[i]);
+    }
+    if constexpr (TAIL8) {
+        if constexpr (GELU) rq_gelu_tanh4(ht);
+        const half8 t8 = {ht[0], ht[1], ht[2], ht[3], ht[0], ht[1], ht[2], ht[3]};
+        mn = NF == 0 ? t8 : __builtin_elementwise_min(mn, t8);
+        mx = NF == 0 ? t8 : __builtin_elementwise_max(mx, t8);
+    }
+    float vmin = (float)mn[0], vmax = (float)mx[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) {
+        vmin = fminf(vmin, (float)mn[e]);
+        vmax = fmaxf(vmax, (float)mx[e]);
+    }
+    vmin = wave_min_f(vmin);
+    vmax = wave_max_f(vmax);
+    __shared__ float pm[RQF_WAVES][2];
+    __shared__ int ps[RQF_WAVES];
+    if (lane == 0) {
+        pm[wv][0] = vmin;
+        pm[wv][1] = vmax;
+    }
+    __syncthreads();
+    vmin = fminf(vmin, pm[wv ^ 1][0]);
+    vmax = fmaxf(vmax, pm[wv ^ 1][1]);
+    float delta, zp;
+    bool small;
+    float inv;
+    vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
+    if (small && lane == 0 && half == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
+    const int izx = (int)zp - cx;
+
+    int8_t* qrow = xq + (size_t)tok * C + half * HC;
+    uint32_t csum = 0;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[i][e];
+        uint2 p;
+        csum += rq_quant8(v, inv, delta, zp, qmax, flip, p);
+        if (live) *reinterpret_cast<uint2*>(qrow + lane * 8 + i * 512) = p;
+    }
+    if constexpr (TAIL8) {
+        const float x4[4] = {(float)ht[0], (float)ht[1], (float)ht[2], (float)ht[3]};
+        uint32_t pk;
+        if (qmax == 255.0f) pk = rq_quant4<true>(x4, inv, delta, zp, qmax);
+        else pk = rq_quant4<false>(x4, inv, delta, zp, qmax);
+        csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
+        if (live) *reinterpret_cast<uint32_t*>(qrow + NF * 512 + lane * 4) = pk ^ flip;
+    }
+    const int rs_half = wave_sum_i((int)csum);
+    if (lane == 0) ps[wv] = rs_half;
+    __syncthreads();
+    if (lane == 0 && half == 0 && live) {
+        sx[tok] = delta;
+        zx[tok] = izx;
+        R[tok] = rs_half + ps[wv ^ 1] - cx * C - C * izx;
     }
 }
 
@@ -1138,6 +1251,14 @@ bool vq_gelu_rowquant_fast(const half_t* x, const float* s, const float* s_rcp, 
     if (s && s_rcp && C > 1536 && n_tok >= 64 &&
         launch_rq_smooth_lds<true>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st))
         return true;
+    // C = 4608 (the fc2 input of the XL models): the row split over two partner waves.  VQ_RQ_SPLIT=0 keeps the
+    // one-row-per-wave kernel (A/B measurements; bit-identical outputs)
+    static const bool no_split = getenv("VQ_RQ_SPLIT") && atoi(getenv("VQ_RQ_SPLIT")) == 0;
+    if (!s && !no_split && C == 4608 && Kp == C && n_tok >= 2) {
+        hipLaunchKernelGGL((rowquant_split_kernel<4, true, true>), dim3((n_tok + RQF_WAVES / 2 - 1) / (RQF_WAVES / 2)),
+                           dim3(RQF_THREADS), 0, st, x, xq, sx, zx, R, n_tok, n_bits, status);
+        return true;
+    }
     dim3 grid((n_tok + RQF_WAVES - 1) / RQF_WAVES), block(RQF_THREADS);
 #define RQG_GO(M_, S_)                                                                                            \
     hipLaunchKernelGGL((rowquant_fast_kernel<M_, S_, false, true>), grid, block, 0, st, x, (const half_t*)nullptr, 1, s, \
