@@ -80,6 +80,11 @@ def _sysfs_gpu(index):
             if os.path.exists(os.path.join(hw, n)):
                 f[key] = os.path.join(hw, n)
                 break
+    # the DPM tables of the fabric / SoC / memory clocks (current level marked '*'): HBM-bound kernels have come out 15-30 %
+    # apart between boxes at EQUAL shader clock, power and temperature - if a box runs its fabric slower it shows here
+    for key, name in (("fclk_mhz", "pp_dpm_fclk"), ("socclk_mhz", "pp_dpm_socclk"), ("mclk_dpm_mhz", "pp_dpm_mclk")):
+        if os.path.exists(os.path.join(dev_dir, name)):
+            f["_dpm_" + key] = os.path.join(dev_dir, name)
     if f:
         f["_card"] = os.path.basename(os.path.dirname(dev_dir)) + " @ " + pick[0][0]
     return f or None
@@ -88,6 +93,16 @@ def _sysfs_gpu(index):
 def _read_sysfs(files):
     out = {}
     for k, path in files.items():
+        if k.startswith("_dpm_"):
+            try:
+                import re
+                cur = [ln for ln in open(path).read().splitlines() if "*" in ln]
+                m = re.search(r"(\d+)\s*mhz", cur[0].lower()) if cur else None
+                if m:
+                    out[k[5:]] = float(m.group(1))
+            except OSError:
+                pass
+            continue
         if k.startswith("_"):
             continue
         try:
@@ -219,11 +234,39 @@ def gemm_clock_probe(dev, burst=24, reps=7):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def memory_probe(dev):
+    """What the box's memory system delivers right now, beside the rates of the HBM-bound kernels: a 1 GiB device copy
+    (HBM: 2 GiB of traffic per copy) and a 48 MiB one (resident in the 256 MiB Infinity Cache after the first pass), best of
+    the timed repetitions.  Boxes of one pool have differed by 15-30 % here at equal shader clock and power."""
+    try:
+        out = {}
+        for name, nbytes, reps in (("hbm_copy_1GiB_TBps", 1 << 30, 6), ("mall_copy_48MiB_TBps", 48 << 20, 40)):
+            a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            b = torch.empty_like(a)
+            b.copy_(a)
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    b.copy_(a)
+                e1.record()
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) * 1e-3 / reps
+                best = t if best is None or t < best else best
+            out[name] = round(2.0 * nbytes / best / 1e12, 3)
+            del a, b
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def leg_telemetry(tel, before, during, dev):
-    """what a leg records: readings before / during / after its timed region + the GEMM's own clock right after it"""
+    """what a leg records: readings before / during / after its timed region, the GEMM's own clock and the memory system's
+    copy rates right after it"""
     clock = gemm_clock_probe(dev)
     return {"source": tel.source, "before": before, "during_timed_region": during, "after": tel.snapshot(),
-            "gemm_shader_clock": clock}
+            "gemm_shader_clock": clock, "memory": memory_probe(dev)}
 
 
 

@@ -4,7 +4,7 @@
 set -u
 OUT=$1; R=$2; shift 2
 mkdir -p $OUT
-FLAGS="--steps 20 --warmup 3 --no-extras --no-cpu-baseline"
+FLAGS="--steps 20 --warmup 3 --no-extras --no-cpu-baseline ${AB_FLAGS:-}"
 for r in $(seq 1 $R); do
   for spec in "$@"; do
     name=${spec%%:*}; envs=${spec#*:}
@@ -21,10 +21,13 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "*.json"))):
     t = d.get("telemetry") or {}
     du = t.get("during_timed_region") or {}
     clk = (t.get("gemm_shader_clock") or {})
-    print("%-14s %.2f steps/s  %.2f ms/step  gemm avg %.1f us frac %.3f  gemm clock %s (%s..%s) GHz  power %s W  sclk %s MHz  temp %s C" % (
+    mem = t.get("memory") or {}
+    print("%-14s %.2f steps/s  %.2f ms/step  gemm avg %.1f us frac %.3f  gemm clock %s (%s..%s) GHz  power %s W  sclk %s MHz  temp %s C  fclk %s  copy %s / %s TB/s" % (
         os.path.basename(f)[:-5], d["value"], d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"],
         clk.get("ghz"), clk.get("ghz_min"), clk.get("ghz_max"),
         ("%.0f" % du["power_w"]["mean"]) if isinstance(du.get("power_w"), dict) else du.get("power_w", "-"),
         ("%.0f" % du["sclk_mhz"]["mean"]) if isinstance(du.get("sclk_mhz"), dict) else du.get("sclk_mhz", "-"),
-        ("%.0f" % du["temp_c"]["max"]) if isinstance(du.get("temp_c"), dict) else du.get("temp_c", "-")))
+        ("%.0f" % du["temp_c"]["max"]) if isinstance(du.get("temp_c"), dict) else du.get("temp_c", "-"),
+        ("%.0f" % du["fclk_mhz"]["mean"]) if isinstance(du.get("fclk_mhz"), dict) else "-",
+        mem.get("hbm_copy_1GiB_TBps", "-"), mem.get("mall_copy_48MiB_TBps", "-")))
 PY

@@ -67,7 +67,8 @@ def short(k):
                  ("attn_fwd32d_kernel", "spatial attention (flash, 1024 keys)"), ("attn_fwd8_kernel", "spatial attention, previous generation"), ("attn_temporal_quant", "temporal attention + proj quantizer"),
                  ("attn_cross_reg", "cross attention (K/V^T in registers)"), ("attn_cross32", "cross attention (K/V resident in LDS)"),
                  ("fp_linear_kernel", "FP edge Linears (embedders, t_block, final layer, patch embedding)"), ("ln_modulate_rowquant_half", "LN + modulate + quantizer C=1152"),
-                 ("rowquant_half", "per-token quantizer C=1152"), ("rowquant_fast_kernelILi9", "per-token quantizer C=4608")):
+                 ("rowquant_half", "per-token quantizer C=1152"), ("rowquant_split", "per-token quantizer C=4608"),
+                 ("rowquant_fast_kernelILi9", "per-token quantizer C=4608")):
         if a in k:
             return b
     return None

@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(64 * NW, NQ == 2 ? 1 : 8 / NW) void attn_fwd8_kerne
 typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));   // operand type of the LDS transpose read
 
 template <int D, int ABLD = 0, int NW = 8, int KT = 64>
-__global__ __launch_bounds__(64 * NW, 32 / NW) void attn_fwd32d_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_fwd32d_kernel(AttnArgs a) {
     static_assert(KT % 64 == 0, "key tile in 64-row DMA units");
     constexpr int KTB = (KT / 64) * Att8Cfg<D, 8>::KTILE;      // K tile bytes
     using C = Att8Cfg<D, NW>;
@@ -1837,7 +1837,11 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         // long query sequences: 32 queries per wave, LDS-DMA tiles, four waves per SIMD (attn_fwd32d_kernel; its buffer
         // loads carry 32-bit byte offsets).  VQ_ATTN_LONG=8 keeps the previous generation for A/B measurements.
         static const bool gen8 = getenv("VQ_ATTN_LONG") && atoi(getenv("VQ_ATTN_LONG")) == 8;
-        if (!gen8 && a.Lq >= 192 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31)) return launch_attn32d<D>(a, st);
+        // VQ_ATTN_NW=4 (measurement arm, round 5): four waves per workgroup - three independent workgroups per CU by LDS
+        // instead of two lock-stepped groups of eight
+        static const bool nw4 = getenv("VQ_ATTN_NW") && atoi(getenv("VQ_ATTN_NW")) == 4;
+        if (!gen8 && a.Lq >= 192 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31))
+            return (nw4 && D == 72) ? launch_attn32d<D, 4>(a, st) : launch_attn32d<D>(a, st);
         return a.Lq >= 192 ? launch_attn8<D, 8>(a, st) : launch_attn8<D, 4>(a, st);
     }
     using C = AttCfg<D>;

@@ -59,13 +59,22 @@ struct GemmArgs {
 
 // Workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (bid % 8), each with its own 4 MiB
 // L2, so XCD x takes a CONTIGUOUS range of the tile order below and the 32 tiles it runs at a time share
-// operands through that L2.  Order: super-rows of 8 token tiles; inside a super-row, groups of 4 channel
-// tiles, token tile fastest.  One round of an XCD is then 8 token panels (8 x 256 x K bytes, re-used by
-// every later group of the super-row) x 4 weight panels, 3.7 MB at K = 1152 - instead of 2 token panels x
-// ALL weight panels (5.9 MB at N = 4608, measured 8x over-fetch of the fc1 operands from the fabric:
-// profiles/r01_hbm_traffic.md).  Bijective for any tile counts.
+// operands through that L2.  Order: super-rows of SM token tiles; inside a super-row, groups of SN channel
+// tiles, token tile fastest.  One round of an XCD is then a few token panels x a few weight panels, 3.7-3.8 MB
+// at K = 1152 - instead of 2 token panels x ALL weight panels (5.9 MB at N = 4608, measured 8x over-fetch of the
+// fc1 operands from the fabric: profiles/r01_hbm_traffic.md).  Bijective for any tile counts.
+// SM x SN = 8 x 4.  Round 5 measured 4 x 8 and 16 x 2 against it inside the two-stream step (alternating on one box, twice):
+// 4 x 8 shortens the GEMM launch average by 1-2 % (58.4 vs 59.0 us, 57.3 vs 58.5 us) at EQUAL step time and moves 8 % more
+// fabric bytes per launch (169.6 vs 156.7 MB: the channel-heavy round re-fetches token panels), 16 x 2 loses 2 % of the
+// step: 8 x 4 stays (profiles/r05_experiments.md).  VQ_XCD_SM / VQ_XCD_SN: A/B builds of other panel shapes.
+#ifndef VQ_XCD_SM
+#define VQ_XCD_SM 8
+#endif
+#ifndef VQ_XCD_SN
+#define VQ_XCD_SN 4
+#endif
 __device__ __forceinline__ void xcd_tile(int bid, int MT, int NTl, int& mt, int& nt) {
-    constexpr int SM = 8, SN = 4;
+    constexpr int SM = VQ_XCD_SM, SN = VQ_XCD_SN;
     const int T = MT * NTl;
     const int q8 = T / 8, r8 = T % 8, xcd = bid % 8, idx = bid / 8;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;

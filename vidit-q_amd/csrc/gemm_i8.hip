@@ -59,7 +59,7 @@ static bool vq_use_12w(const GemmArgs& a, int sets) {
 // kernel with asymmetric DMA issue (gemm_wide.h, INT 1: waves 0-3 issue every stage piece): `variant` 19, and the library's
 // own choice for such shapes - every Linear of the benchmarked STDiT / PixArt-Sigma configurations.  Bit-identical to the
 // general form (tested).  VQ_GEMM_INT = 0 keeps the general form everywhere, 2 selects the measurement arm (scalar
-// addressing, every wave issuing) - A/B runs on one box.
+// addressing, every wave issuing), 3 the half-slab epilogue (136 KiB of LDS per workgroup) - A/B runs on one box.
 static int vq_int_mode() {
     static const int mode = getenv("VQ_GEMM_INT") ? atoi(getenv("VQ_GEMM_INT")) : 1;
     return mode;
@@ -72,6 +72,13 @@ static int launch_gemm_auto(const GemmArgs& a, hipStream_t st, int variant) {
     const bool interior = a.M % bm == 0 && a.N % 288 == 0;
     const int im = variant == 19 ? 1 : (variant == VQ_GEMM_DEFAULT && interior) ? vq_int_mode() : 0;
     if (variant == 19 && !interior) return VQ_ESHAPE;
+    // the twelve-wave form (VQ_GEMM_12W, off by default) in its interior form as well: scalar addressing, six issuing waves
+    if (im != 0 && !half && variant == VQ_GEMM_DEFAULT && vq_use_12w(a, sets)) return launch_gemm_wide<256, 288, 4, 3, true, W4, 1>(a, st);
+    if (im == 3) {   // half epilogue slabs: exist for the interior EPILOGUE only (8-byte aligned rows, gate folded into the scales)
+        const bool ok = !half && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (a.epilogue != VQ_EPI_GATE_RESID || a.rows_per_gate % 256 == 0);
+        if (ok) return launch_gemm_wide<256, 288, 4, 2, true, W4, 3>(a, st);
+        return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 1>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 1>(a, st);
+    }
     if (im == 1) return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 1>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 1>(a, st);
     if (im == 2) return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 2>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 2>(a, st);
     if (half) return launch_gemm_wide<128, 288, 4, 2, true, W4>(a, st);

@@ -8,6 +8,12 @@
 #ifndef VQ_GEMM_FP_DEQUANT
 #define VQ_GEMM_FP_DEQUANT true
 #endif
+#ifndef VQ_GEMM_YOUNG_ISSUERS
+#define VQ_GEMM_YOUNG_ISSUERS 0
+#endif
+#ifndef VQ_GEMM_LATE_STAGE1
+#define VQ_GEMM_LATE_STAGE1 1      // round 5: +0.5 % steps/s in an A/B on one box (25.60 / 25.70 vs 25.54 / 25.51), gemm_wide.h prologue
+#endif
 
 // ---------------------------------------------------------------------------
 // Full-line ring kernel (variant 11).  tools/dma_depth.py: the L2 -> LDS fill rate of a CU is bound by
@@ -29,13 +35,18 @@
 // wave share one parity) + a SCALAR row / k offset in the buffer instruction's soffset - 2 VGPRs instead of 9 - and
 //   INT 1: waves 0 .. NW/2-1 (one per SIMD) issue EVERY piece of a stage right behind the stage barrier, their SIMD partners
 //          none ("asymmetric issue": the closest a 240-register kernel gets to a loader role, profiles/r05_gemm_loader.md);
-//   INT 2: every wave issues its share, staggered as in the general form (measurement arm: addressing alone).
+//   INT 2: every wave issues its share, staggered as in the general form (measurement arm: addressing alone);
+//   INT 3: INT 1 with the epilogue through half slabs (interior epilogue only: the launcher checks what that needs).
 // Same stages, fragment reads, MFMA order and epilogue: bit-identical results (tested); back to back 2-4 % faster on the
 // single-round launches and 14 % on fc1 / fc2 (main loop 1479 -> 1399 cycles per k-step, prologue 5.1 k -> 4.0 k cycles).
+// (Tried on top and NOT kept: the non-issuing waves requesting the tile's dequantisation parameters during their idle prologue,
+//  11 more VGPRs through the loop - the step lost 2.2 %, GEMM launch average 59.6 -> 61.6 us in an A/B on one box: parameter
+//  requests at kernel entry stand in front of the first stage's cold misses.  gpurun_out/r5d, profiles/r05_experiments.md.)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0, int INT = 0>
 __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, const int tid_) {
     constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int NI = INT == 1 ? NW / 2 : NW;        // issuing waves
+    constexpr bool ASYM = INT == 1 || INT == 3;       // one issuing wave per SIMD (INT 3: + half epilogue slabs, below)
+    constexpr int NI = ASYM ? NW / 2 : NW;            // issuing waves
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int WROW = W4 ? 64 : 128;               // bytes per weight row and stage
@@ -49,7 +60,9 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (next tile)
     static_assert((TM == 8 || TM == 4 || TM == 2) && TN >= 3 && TN % 3 == 0, "fragment rings below");
     // more than 8 waves: full epilogue slabs (NW x WTM rows) no longer fit beside the parameter blocks - half slabs
-    constexpr int SROWS = NW > 8 ? WTM / 2 : 0;
+    // INT 3 (measurement arm / option): the 8-wave interior form with HALF slabs too - 136 KiB of LDS instead of all 160, so
+    // that workgroups of the other stream's kernels which need a little LDS can become resident beside a GEMM workgroup
+    constexpr int SROWS = (NW > 8 || INT == 3) ? WTM / 2 : 0;
     constexpr int SLROWS = SROWS ? SROWS : WTM;
     static_assert(BN * WROW % 1024 == 0 && STAGE % 128 == 0, "whole pieces, 128-byte aligned stages");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
@@ -101,15 +114,18 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const bool full_wave = (PIECES % NI == 0) || wave < PLAST;
-    const bool issuer = wave < NI;                    // wave-uniform (INT 1: one wave per SIMD)
-    const bool late = INT != 1 && STAGGER && wave >= NW / 2;      // wave-uniform
+    const bool full_wave = (PIECES % NI == 0) || (((ASYM && VQ_GEMM_YOUNG_ISSUERS) ? wave - (NW - NI) : wave) < PLAST);
+    // (INT 1: one wave per SIMD issues.  VQ_GEMM_YOUNG_ISSUERS=1 gives the role to the later-dispatched half, waves NW/2.. -
+    //  measurement arm, round 5)
+    const bool issuer = (ASYM && VQ_GEMM_YOUNG_ISSUERS) ? wave >= NW - NI : wave < NI;       // wave-uniform
+    const int li = (ASYM && VQ_GEMM_YOUNG_ISSUERS) ? wave - (NW - NI) : wave;                // index among the issuing waves
+    const bool late = !ASYM && STAGGER && wave >= NW / 2;         // wave-uniform
 
     uint32_t soff[INT ? 2 : PPW];
     if constexpr (INT != 0) {
         // [0]: token rows (128-byte stage rows), [1]: weight rows (W4: 64-byte rows, 16 per piece - its swizzle phase
         // (row >> 2) & 3 = (lane >> 4) & 3 does not depend on the piece at all)
-        soff[0] = (uint32_t)(lane >> 3) * (uint32_t)a.Kp + (uint32_t)(((lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7)) * 16);
+        soff[0] = (uint32_t)(lane >> 3) * (uint32_t)a.Kp + (uint32_t)(((lane & 7) ^ (((li & 1) * 4 + (lane >> 4)) & 7)) * 16);
         soff[1] = W4 ? (uint32_t)(lane >> 2) * (uint32_t)(a.Kp >> 1) + (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16) : soff[0];
     }
 #pragma unroll
@@ -151,7 +167,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
         if constexpr (INT != 0) {
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
-                const int p = wave + i * NI;
+                const int p = li + i * NI;
                 if (PIECES % NI == 0 || p < PIECES) {
                     const unsigned dst = lds0 + stage * STAGE + p * 1024;
                     if (p < XP) {
@@ -216,9 +232,14 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     };
 
     const int nkt = a.Kp / 128;
-    if (INT != 1 || issuer) {
+    // VQ_GEMM_LATE_STAGE1 (INT 1 / 3): the issuing waves request only stage 0 before the first barrier and stage 1 right
+    // behind it - the 17 pieces of stage 1 (~950 cycles of issue per wave) leave the prologue, where nothing covers them,
+    // for the head of the main loop, where the partner wave owns the matrix pipe meanwhile; stage 1 is first read a whole
+    // k-tile later (behind the vmcnt(0) + barrier of tile 0)
+    constexpr bool LATE1 = ASYM && VQ_GEMM_LATE_STAGE1;
+    if (!ASYM || issuer) {
         issue(0, 0);
-        if (nkt > 1) {
+        if (nkt > 1 && !LATE1) {
             issue(1, 1);
             if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW - 1) : "memory");
@@ -227,6 +248,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
         }
     }
     __builtin_amdgcn_s_barrier();
+    if (LATE1 && issuer && nkt > 1) issue(1, 1);
     if (ts) ts[1] = __builtin_readcyclecounter();
     int4v xa[TM], xb[TM];
     WRaw w[3];
@@ -242,7 +264,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
                 __builtin_amdgcn_sched_barrier(0);                                                         \
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
                 if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                              \
-                if (!(ABL & 1) && !late && (INT != 1 || issuer) && kt + 2 < nkt) issue(cur, kt + 2);                     \
+                if (!(ABL & 1) && !late && (!ASYM || issuer) && kt + 2 < nkt) issue(cur, kt + 2);                        \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
             }                                                                                              \
             if (!(ABL & 1) && H == 0 && j == DMA_B && late && kt >= 1 && more) {                                         \
@@ -311,7 +333,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool 
 static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t RING = 2 * ((size_t)BM * 128 + (size_t)BN * (W4 ? 64 : 128));
-    constexpr int SLROWS = WAVES_M * WAVES_N > 8 ? BM / WAVES_M / 2 : BM / WAVES_M;      // half slabs beyond 8 waves (gemm_i8_wide_tile)
+    constexpr int SLROWS = (WAVES_M * WAVES_N > 8 || INT == 3) ? BM / WAVES_M / 2 : BM / WAVES_M;   // half slabs (gemm_i8_wide_tile)
     constexpr size_t EPIL = (size_t)WAVES_M * WAVES_N * SLROWS * ((BN / WAVES_N) * 2 + 16) + 4 * BN * 4 + 12 * BM;
     constexpr size_t LDS = RING > EPIL ? RING : EPIL;
     static_assert(LDS <= 163840, "LDS budget of one CU");

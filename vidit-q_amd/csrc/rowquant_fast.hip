@@ -1248,12 +1248,15 @@ static void launch_lnq(int n_out, dim3 grid, hipStream_t st, const half_t* x, co
 bool vq_gelu_rowquant_fast(const half_t* x, const float* s, const float* s_rcp, int8_t* xq, float* sx, int32_t* zx,
                            int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
     if (C > 4608 || Kp > 4608) return false;
+    // C = 4608 (the fc2 input of the XL models), no smoothing: the row split over two partner waves.  VQ_RQ_SPLIT=0 keeps the
+    // one-row-per-wave kernel (A/B measurements; bit-identical outputs).  (The SMOOTHED long-row kernel below - persistent
+    // workgroups, vectors in LDS, next row in flight - was also built in the split form, bit-identical, and the W4A8 step
+    // lost 0.8 % with it in an A/B on one box (23.75 vs 23.56 steps/s, profiles/r05_experiments.md): it already overlaps its
+    // loads with its arithmetic, the split only added a barrier per row.  Not kept.)
+    static const bool no_split = getenv("VQ_RQ_SPLIT") && atoi(getenv("VQ_RQ_SPLIT")) == 0;
     if (s && s_rcp && C > 1536 && n_tok >= 64 &&
         launch_rq_smooth_lds<true>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st))
         return true;
-    // C = 4608 (the fc2 input of the XL models): the row split over two partner waves.  VQ_RQ_SPLIT=0 keeps the
-    // one-row-per-wave kernel (A/B measurements; bit-identical outputs)
-    static const bool no_split = getenv("VQ_RQ_SPLIT") && atoi(getenv("VQ_RQ_SPLIT")) == 0;
     if (!s && !no_split && C == 4608 && Kp == C && n_tok >= 2) {
         hipLaunchKernelGGL((rowquant_split_kernel<4, true, true>), dim3((n_tok + RQF_WAVES / 2 - 1) / (RQF_WAVES / 2)),
                            dim3(RQF_THREADS), 0, st, x, xq, sx, zx, R, n_tok, n_bits, status);
