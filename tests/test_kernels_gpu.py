@@ -859,33 +859,35 @@ def test_gelu_rowquant_matches_gelu_then_rowquant(ops, dev, C, smooth):
     assert rel_l2(deq.cpu(), ref.cpu()) < 1e-2      # 8-bit quantization noise itself
 
 
-@pytest.mark.parametrize("smooth", [False])
-def test_gelu_rowquant_split_rows_are_bit_identical_to_one_row_per_wave(ops, dev, tmp_path, smooth):
+SPLIT_CASES = ((1, 301, 8), (1, 301, 6), (1, 16384, 8), (2, 515, 8), (2, 4096, 6))
+
+
+def test_gelu_rowquant_split_rows_are_bit_identical_to_one_row_per_wave(ops, dev, tmp_path):
     """Round 5: at C = 4608 a row is split over two partner waves (rowquant_split_kernel: min / max and code sums exchanged
-    through LDS).  Against the one-row-per-wave kernel, selected in a child process by VQ_RQ_SPLIT=0 (the switch is read once
-    per process): codes, steps, zero points and row sums equal bit for bit - 8 and 6 bits, an odd row count (a workgroup whose
-    second pair idles through the barriers), 16384 rows."""
+    through LDS; B = 2: the four waves of a workgroup are (sample, half) of one token).  Against the one-row-per-wave kernels,
+    selected in a child process by VQ_RQ_SPLIT=0 (the switch is read once per process): codes, steps, zero points and row sums
+    equal bit for bit - 8 and 6 bits, an odd row count (a workgroup whose second pair idles through the barriers), 16384
+    rows, the uncond | cond pair."""
     import subprocess
     import sys
     code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import viditq_amd; from viditq_amd import ops; "
             "import test_kernels_gpu as t; dev = torch.device('cuda:0'); out = {}\n"
-            "for n_tok, bits in ((301, 8), (301, 6), (16384, 8)):\n"
-            "    h = t.h16(1, n_tok, 4608, scale=2.0, seed=n_tok + bits).to(dev)\n"
-            "    s = (torch.rand(4608, generator=torch.Generator().manual_seed(1)) + 0.5).float().to(dev) if %r else None\n"
-            "    q = ops.gelu_rowquant(h, n_bits=bits, s=s)\n"
-            "    out[(n_tok, bits)] = [x.cpu() for x in (q.xq, q.sx, q.zx, q.R)]\n"
-            "torch.save(out, sys.argv[1])\n" % (ROOT, os.path.join(ROOT, "tests"), smooth))
+            "for B, n_tok, bits in t.SPLIT_CASES:\n"
+            "    h = t.h16(B, n_tok, 4608, scale=2.0, seed=n_tok + bits).to(dev)\n"
+            "    q = ops.gelu_rowquant(h, n_bits=bits)\n"
+            "    out[(B, n_tok, bits)] = [x.cpu() for x in (q.xq, q.sx, q.zx, q.R)]\n"
+            "torch.save(out, sys.argv[1])\n" % (ROOT, os.path.join(ROOT, "tests")))
     f = str(tmp_path / "one_row.pt")
     r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, VQ_RQ_SPLIT="0"), capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     ref = torch.load(f)
-    for (n_tok, bits), want in ref.items():
-        h = h16(1, n_tok, 4608, scale=2.0, seed=n_tok + bits).to(dev)
-        s = (torch.rand(4608, generator=torch.Generator().manual_seed(1)) + 0.5).float().to(dev) if smooth else None
-        q = ops.gelu_rowquant(h, n_bits=bits, s=s)
+    assert len(ref) == len(SPLIT_CASES)
+    for (B, n_tok, bits), want in ref.items():
+        h = h16(B, n_tok, 4608, scale=2.0, seed=n_tok + bits).to(dev)
+        q = ops.gelu_rowquant(h, n_bits=bits)
         for got, w in zip((q.xq, q.sx, q.zx, q.R), want):
-            assert torch.equal(got.cpu(), w), (n_tok, bits)
+            assert torch.equal(got.cpu(), w), (B, n_tok, bits)
 
 
 @pytest.mark.parametrize("C,n_tok,smooth", [(4608, 515, False), (4608, 300, True), (1152, 131, False), (320, 65, False)])

@@ -255,16 +255,20 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_fast_kernel(
 // (rq_gelu_tanh8, packed fp16 min / max, vq_row_grid, rq_round_group): bit-identical outputs (tested).
 // C / 2 = NF * 512 + (TAIL8 ? 256 : 0) channels per wave: NF 16-byte loads per lane + one 8-byte load.
 // ---------------------------------------------------------------------------
-template <int NF, bool TAIL8, bool GELU>
+// PAIR: x [2, n_tok, C] with the grid of a token shared by its two samples (the t2i uncond | cond forward): the four waves of a
+// workgroup are (sample, half) of ONE token - min / max over all four, code sums per sample.
+template <int NF, bool TAIL8, bool GELU, bool PAIR = false>
 __global__ __launch_bounds__(RQF_THREADS) void rowquant_split_kernel(const half_t* __restrict__ x, int8_t* __restrict__ xq,
                                                                      float* __restrict__ sx, int32_t* __restrict__ zx,
                                                                      int32_t* __restrict__ R, int n_tok, int n_bits,
                                                                      int32_t* status) {
+    static_assert(!PAIR || RQF_WAVES == 4, "(sample, half) = the four waves of a workgroup");
     constexpr int HC = NF * 512 + (TAIL8 ? 256 : 0), C = 2 * HC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = wv & 1;
-    int tok = blockIdx.x * (RQF_WAVES / 2) + (wv >> 1);
+    int tok = PAIR ? blockIdx.x : blockIdx.x * (RQF_WAVES / 2) + (wv >> 1);
     const bool live = tok < n_tok;
     if (!live) tok = n_tok - 1;                        // stays for the workgroup barriers, writes nothing
+    if (PAIR && (wv >> 1)) tok += n_tok;               // row index of (sample 1, token)
     const float qmax = (float)((1 << n_bits) - 1);
     const int cx = (n_bits == 8) ? 128 : 0;
     const uint32_t flip = (n_bits == 8) ? 0x80808080u : 0u;
@@ -303,13 +307,21 @@ __global__ __launch_bounds__(RQF_THREADS) void rowquant_split_kernel(const half_
         pm[wv][1] = vmax;
     }
     __syncthreads();
-    vmin = fminf(vmin, pm[wv ^ 1][0]);
-    vmax = fmaxf(vmax, pm[wv ^ 1][1]);
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int w = 0; w < RQF_WAVES; ++w) {
+            vmin = fminf(vmin, pm[w][0]);
+            vmax = fmaxf(vmax, pm[w][1]);
+        }
+    } else {
+        vmin = fminf(vmin, pm[wv ^ 1][0]);
+        vmax = fmaxf(vmax, pm[wv ^ 1][1]);
+    }
     float delta, zp;
     bool small;
     float inv;
     vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
-    if (small && lane == 0 && half == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
+    if (small && lane == 0 && (PAIR ? wv == 0 : half == 0) && live && status) atomicOr(status, VQ_ST_EPSFILL);
     const int izx = (int)zp - cx;
 
     int8_t* qrow = xq + (size_t)tok * C + half * HC;
@@ -1282,6 +1294,13 @@ bool vq_gelu_rowquant_pair_fast(const half_t* x, const float* s, const float* s_
     if (s && s_rcp && C > 1536 && n_tok >= 2 &&
         launch_rq_smooth_lds<true, true>(x, s, s_rcp, xq, sx, zx, R, n_tok, C, Kp, n_bits, status, st))
         return true;
+    // C = 4608 without smoothing: the (sample, half) split - four waves per token (VQ_RQ_SPLIT=0: one row per wave)
+    static const bool no_split = getenv("VQ_RQ_SPLIT") && atoi(getenv("VQ_RQ_SPLIT")) == 0;
+    if (!s && !no_split && C == 4608 && Kp == C) {
+        hipLaunchKernelGGL((rowquant_split_kernel<4, true, true, true>), dim3(n_tok), dim3(RQF_THREADS), 0, st, x, xq, sx, zx, R, n_tok,
+                           n_bits, status);
+        return true;
+    }
     // every other smoothed case - a vector without a usable reciprocal (vq_smooth_reciprocal flagged a channel, or an
     // unseen vector under graph capture: s_rcp == nullptr -> IEEE division, as B = 1 falls back), short rows - takes the
     // register kernel with the smoothing operands from global memory, like the un-smoothed pair
