@@ -377,7 +377,10 @@ __device__ __forceinline__ void ring_epilogue_interior(const GemmArgs& a, uint8_
 
 // Shared epilogue of the LDS-DMA ring kernels (called after a workgroup barrier; uses all of smem; the
 // parameter block must have been staged by ring_stage_params and made visible by that barrier).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16, bool FP = false, int SROWS = 0>
+// INTERIOR_ONLY: the launcher guarantees what the interior path needs for EVERY tile (interior tiles, 8-element aligned rows,
+// the gate folded into the staged scales) - the general path below is then not even compiled into the kernel: the resid
+// epilogues' 18 x 16-byte residual registers of that path were what put those kernels at 244 VGPRs (round 5).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int PAD = 16, bool FP = false, int SROWS = 0, bool INTERIOR_ONLY = false>
 __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
                                               int4v (&acc)[BN / WAVES_N / 16][BM / WAVES_M / 16], int m0, int n0,
                                               long long* ts = nullptr, int tid_in = -1, bool gate_folded = false) {
@@ -389,6 +392,10 @@ __device__ __forceinline__ void ring_epilogue(const GemmArgs& a, uint8_t* smem,
     constexpr int TM = WTM / 16, TN = WTN / 16;
     const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
     if constexpr ((BM / WAVES_M) * (BN / WAVES_N / 8) % 64 == 0) {
+        if constexpr (INTERIOR_ONLY) {
+            ring_epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, PAD, FP, SROWS>(a, smem, acc, m0, n0, tid);
+            return;
+        }
         // workgroup-uniform: every tile of the benchmark shapes is interior and takes the lean path
         const bool interior = m0 + BM <= a.M && n0 + BN <= a.N && (a.N & 7) == 0 && (a.ldo & 7) == 0 &&
                               (EPI != VQ_EPI_GATE_RESID || gate_folded);

@@ -69,14 +69,14 @@ static int launch_gemm_auto(const GemmArgs& a, hipStream_t st, int variant) {
     const int sets = a.nbatch > 1 ? a.nbatch : a.ngroups > 1 ? a.ngroups : 1;
     const bool half = variant == 16 || (variant == VQ_GEMM_DEFAULT && vq_half_tiles(a.M, a.N, sets));
     const int bm = half ? 128 : 256;
-    const bool interior = a.M % bm == 0 && a.N % 288 == 0;
+    const bool interior = a.M % bm == 0 && a.N % 288 == 0 && (a.ldo & 7) == 0 &&
+                          (a.epilogue != VQ_EPI_GATE_RESID || a.rows_per_gate % bm == 0);   // what the interior form's epilogue needs
     const int im = variant == 19 ? 1 : (variant == VQ_GEMM_DEFAULT && interior) ? vq_int_mode() : 0;
     if (variant == 19 && !interior) return VQ_ESHAPE;
     // the twelve-wave form (VQ_GEMM_12W, off by default) in its interior form as well: scalar addressing, six issuing waves
     if (im != 0 && !half && variant == VQ_GEMM_DEFAULT && vq_use_12w(a, sets)) return launch_gemm_wide<256, 288, 4, 3, true, W4, 1>(a, st);
     if (im == 3) {   // half epilogue slabs: exist for the interior EPILOGUE only (8-byte aligned rows, gate folded into the scales)
-        const bool ok = !half && (a.N & 7) == 0 && (a.ldo & 7) == 0 && (a.epilogue != VQ_EPI_GATE_RESID || a.rows_per_gate % 256 == 0);
-        if (ok) return launch_gemm_wide<256, 288, 4, 2, true, W4, 3>(a, st);
+        if (!half) return launch_gemm_wide<256, 288, 4, 2, true, W4, 3>(a, st);
         return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 1>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 1>(a, st);
     }
     if (im == 1) return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 1>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 1>(a, st);

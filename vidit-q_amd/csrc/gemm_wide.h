@@ -321,7 +321,9 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     ring_park_col_params<BM, BN, WAVES_M, WAVES_N, 16, VQ_GEMM_FP_DEQUANT, SROWS>(colp, smem, tid);
     ring_park_row_params<BM, BN, WAVES_M, WAVES_N, 16, VQ_GEMM_FP_DEQUANT, SROWS>(rowp, smem, tid);
     __syncthreads();
-    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI, 16, VQ_GEMM_FP_DEQUANT, SROWS>(a, smem, acc, m0, n0, ts, tid, gate_row != nullptr);
+    // (INT != 0: the launcher has checked what the interior epilogue needs for every tile - launch_gemm_wide_e)
+    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI, 16, VQ_GEMM_FP_DEQUANT, SROWS, INT != 0 && (ABL & 16) == 0>(a, smem, acc, m0, n0, ts, tid,
+                                                                                                        gate_row != nullptr);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool STAGGER, bool W4, int ABL = 0, int INT = 0>
@@ -339,7 +341,11 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
     static_assert(LDS <= 163840, "LDS budget of one CU");
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
     const int tiles = MT * NTl * (a.nbatch > 1 ? a.nbatch : a.ngroups > 1 ? a.ngroups : 1);
-    if (INT != 0 && (a.M % BM != 0 || a.N % BN != 0)) return VQ_ESHAPE;      // interior tiles only
+    // interior tiles only, and (its epilogue is the interior one, compiled alone) 8-element aligned rows and a gate that folds
+    // into the staged scales for every tile
+    if (INT != 0 && (a.M % BM != 0 || a.N % BN != 0 || (a.N & 7) != 0 || (a.ldo & 7) != 0 ||
+                     (EPI == VQ_EPI_GATE_RESID && a.rows_per_gate % BM != 0)))
+        return VQ_ESHAPE;
     auto k = gemm_i8_wide_kernel<BM, BN, WAVES_M, WAVES_N, EPI, STAGGER, W4, 0, INT>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);  // once
