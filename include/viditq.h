@@ -194,7 +194,8 @@ int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32
  * GEMM actually ran at on THIS box (bench.py reports it beside every rate; a power-bound part runs 1.8-2.1 of its
  * nominal 2.4 GHz).  stamps [tiles][8 waves][10] int64, tiles = ceil(M/256) * ceil(N/288): 0-6 shader cycles at entry /
  * first stage landed / main loop end / parameters staged / slabs written / stores issued / stores drained, 7 and 8 the
- * wall clock at entry and exit (10 ns ticks), 9 unused.  n_stamps = capacity of `stamps` in int64 (VQ_ESHAPE when
+ * wall clock at entry and exit (10 ns ticks), 9 the shader cycle at which the wave arrived at the stage barrier of k-tile 1 (0 when
+ * the problem has fewer than three k-tiles).  n_stamps = capacity of `stamps` in int64 (VQ_ESHAPE when
  * too small).  Outputs equal vq_gemm_i8(..., w_bits 8, VQ_EPI_NONE). */
 int vq_gemm_i8_stamped(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R,
                        const void* wq, const float* sw, const int32_t* zw, const int32_t* cs,

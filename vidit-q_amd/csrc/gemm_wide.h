@@ -11,6 +11,9 @@
 #ifndef VQ_GEMM_YOUNG_ISSUERS
 #define VQ_GEMM_YOUNG_ISSUERS 0
 #endif
+#ifndef VQ_GEMM_WPF
+#define VQ_GEMM_WPF 2
+#endif
 #ifndef VQ_GEMM_LATE_STAGE1
 #define VQ_GEMM_LATE_STAGE1 1      // round 5: +0.5 % steps/s in an A/B on one box (25.60 / 25.70 vs 25.54 / 25.51), gemm_wide.h prologue
 #endif
@@ -56,7 +59,11 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     constexpr int PPW = (PIECES + NI - 1) / NI;
     constexpr int PLAST = PIECES - (PPW - 1) * NI;
     static_assert(INT == 0 || (NI % 2 == 0 && XP % 2 == 0), "one piece parity per issuing wave");
-    constexpr int BARJ = TN - 2;                      // after the last fragment read of the current stage
+    // weight-fragment ring: reads run WPF channel groups ahead of their MFMAs (2 = the ring of three of rounds 1-4;
+    // VQ_GEMM_WPF = 3 / 4 / 5: a ring of six - measurement arm for the lone-wave phases of the interior form)
+    constexpr int WPF = VQ_GEMM_WPF, WR = WPF == 2 ? 3 : 6;
+    static_assert(WPF >= 2 && WPF <= 5 && (2 * TN) % WR == 0 && WPF < TN, "ring index must repeat per stage");
+    constexpr int BARJ = TN - WPF;                    // after the last fragment read of the current stage
     constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (next tile)
     static_assert((TM == 8 || TM == 4 || TM == 2) && TN >= 3 && TN % 3 == 0, "fragment rings below");
     // more than 8 waves: full epilogue slabs (NW x WTM rows) no longer fit beside the parameter blocks - half slabs
@@ -68,7 +75,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // ABL & 16: cycle-counter stamps of every wave -> a.gate reinterpreted as long long[tiles][waves][10] (0-6 shader cycles, 7/8 100 MHz wall clock at start/end)
+    // ABL & 16: cycle-counter stamps of every wave -> a.gate reinterpreted as long long[tiles][waves][10] (0-6 shader cycles, 7/8 100 MHz wall clock at start/end, 9 arrival at the stage barrier of k-tile 1)
     long long* ts = nullptr;
     if constexpr ((ABL & 16) != 0)
         ts = reinterpret_cast<long long*>(const_cast<float*>(a.gate)) + ((size_t)vb0 * (WAVES_M * WAVES_N) + (tid_ >> 6)) * 10;
@@ -251,17 +258,18 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
     if (LATE1 && issuer && nkt > 1) issue(1, 1);
     if (ts) ts[1] = __builtin_readcyclecounter();
     int4v xa[TM], xb[TM];
-    WRaw w[3];
+    WRaw w[WR];
 #pragma unroll
     for (int i = 0; i < TM; ++i) xa[i] = ldx(0, 0, i);
-    w[0] = ldw(0, 0, 0);
-    w[1] = ldw(0, 0, 1);
+#pragma unroll
+    for (int k = 0; k < WPF; ++k) w[k % WR] = ldw(0, 0, k);
 
 #define VQ_WIDE_STEP(X, XN, H)                                                                             \
     {                                                                                                      \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
             if (H == 1 && j == BARJ && more) {                                                             \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
+                if ((ABL & 16) != 0 && ts && kt == 1) ts[9] = __builtin_readcyclecounter(); /* arrival at the second stage barrier */ \
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
                 if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                              \
                 if (!(ABL & 1) && !late && (!ASYM || issuer) && kt + 2 < nkt) issue(cur, kt + 2);                        \
@@ -273,14 +281,14 @@ __device__ __forceinline__ void gemm_i8_wide_tile(GemmArgs a, const int vb0, con
                 __builtin_amdgcn_sched_barrier(0);                                                         \
             }                                                                                              \
             if (ABL & 8) {                                                                                 \
-            } else if (j + 2 < TN) w[(j + 2) % 3] = ldw(cur, H, j + 2);                                    \
-            else if (H == 0) w[(j + 2) % 3] = ldw(cur, 1, j + 2 - TN);                                     \
-            else if (more) w[(j + 2) % 3] = ldw(nxt, 0, j + 2 - TN);                                       \
+            } else if (j + WPF < TN) w[(H * TN + j + WPF) % WR] = ldw(cur, H, j + WPF);                    \
+            else if (H == 0) w[(H * TN + j + WPF) % WR] = ldw(cur, 1, j + WPF - TN);                       \
+            else if (more) w[(H * TN + j + WPF) % WR] = ldw(nxt, 0, j + WPF - TN);                         \
             if (!(ABL & 8) && (H == 0 || more)) {                                                                          \
                 if (j == TN - 2) { _Pragma("unroll") for (int i = 0; i < TM / 2; ++i) XN[i] = ldx(H == 0 ? cur : nxt, 1 - H, i); } \
                 if (j == TN - 1) { _Pragma("unroll") for (int i = TM / 2; i < TM; ++i) XN[i] = ldx(H == 0 ? cur : nxt, 1 - H, i); } \
             }                                                                                              \
-            const int4v wv_ = wop(w[j % 3]);                                                               \
+            const int4v wv_ = wop(w[(H * TN + j) % WR]);                                                   \
             if (ABL & 2) {                                                                                 \
                 asm volatile("" ::"v"(wv_), "v"(X[0]), "v"(X[TM / 2]), "v"(X[TM - 1]));                    \
             } else {                                                                                       \
