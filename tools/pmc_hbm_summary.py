@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 T = os.path.join(ROOT, "gpurun_out", TAG + "_hbm")
 KERNELS = (("attn_cross", "cross attention"), ("attn_temporal_quant", "temporal attention + proj quantizer"),
+           ("rowquant_split_kernel", "per-token quantizer C=4608 + GELU, row split over two partner waves (round 5)"),
            ("rowquant_fast_kernel", "per-token quantizer, one row per wave (C=4608 +GELU; C<=1536 generic)"),
            ("ln_modulate_rowquant_half", "LN + modulate + quantizer C=1152"), ("ln_modulate_rowquant_fast", "LN + modulate + quantizer (final layer)"),
            ("Z20rowquant_half", "per-token quantizer C=1152"), ("rowquant_smooth", "smoothed quantizer"),
