@@ -1,7 +1,9 @@
 """Round 5: the LDS-DMA issue taken off the MFMA waves (tools/lab/gemm_loader.hip) against the product ring kernel.
 mode 0: 256 x 192 tile, 8 MFMA waves of 64 x 96 + 4 dedicated loader waves (3 waves per SIMD, <= 168 VGPRs);
 mode 2: the same tile without loader waves (waves 0-3 issue) - the control; mode 1: the product's 256 x 288 tile with waves
-0-3 issuing every piece.  Bit-identity, back-to-back times at the block's GEMM shapes, ablations, per-wave stamps.  GPU box."""
+0-3 issuing every piece.  Bit-identity, back-to-back times at the block's GEMM shapes, ablations, per-wave stamps.  GPU box.
+(The back-to-back columns are timed in order and the first one follows the shape's host-side set-up: it reads slow by 10-25 % -
+tools/gemm_sp.py times the same forms alternately and warm; the stamps are cycle counts and do not care.)"""
 import os
 import sys
 

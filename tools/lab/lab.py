@@ -34,6 +34,8 @@ def lib():
         _lib.vq_lab_gemm_4w.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
         _lib.vq_lab_gemm_loader.restype = _i
         _lib.vq_lab_gemm_loader.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
+        _lib.vq_lab_gemm_sp.restype = _i
+        _lib.vq_lab_gemm_sp.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
         _lib.vq_probe_mfma_i8.argtypes = [_vp, _vp, _vp, _vp]
         _lib.vq_probe_stage_rate.argtypes = [_i, _vp, _i, _i, _i, _vp, _vp]
         _lib.vq_probe_mfma_rate.argtypes = [_i, _i, _i, _vp, _vp]
@@ -81,6 +83,19 @@ def gemm_loader(a, w, bias=None, out=None, epilogue=0, resid=None, gate=None, ro
                                   epilogue, variant, torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise RuntimeError("vq_lab_gemm_loader mode %d variant %d: error %d" % (mode, variant, rc))
+    return out
+
+
+def gemm_sp(a, w, bias=None, out=None, epilogue=0, resid=None, gate=None, rows_per_gate=0, variant=0, grid=0):
+    """tools/lab/gemm_sp.hip: persistent 256 x 192 tiles, the finished tile's stores fed into the next tile's main loop"""
+    M, N = a.rows, w.N
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=a.xq.device)
+    rc = lib().vq_lab_gemm_sp(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs), _p(bias),
+                              _p(out), out.stride(0), _p(resid), _p(gate), rows_per_gate, M, N, a.K, a.Kp, grid,
+                              epilogue, variant, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("vq_lab_gemm_sp variant %d: error %d" % (variant, rc))
     return out
 
 
