@@ -507,6 +507,48 @@ def test_smoothed_outputs_of_one_pass_equal_the_per_output_kernels(ops, dev, n_t
             assert torch.equal(xm, xm1)
 
 
+SM1_CASES = ((257, 8), (2048, 6), (16384, 8))
+
+
+def test_single_smoothed_output_with_vectors_in_lds_is_bit_identical_to_the_register_kernel(ops, dev, tmp_path):
+    """Round 5: ONE smoothed output (every W4A8 Linear that does not share its input: cross q, the three proj, fc1) also runs
+    smooth_rowquant_multi_kernel<.., NOUT = 1> - smoothing vectors, reciprocals and modulation vectors in LDS, ~96 registers
+    per wave instead of 167 (behind LayerNorm: 248).  Against smooth_rowquant_half_kernel (vectors in registers), selected in
+    a child process by VQ_RQ_SM1=0: the same per-lane expressions in the same order, so codes, steps, zero points, row sums
+    and the modulated activation are equal bit for bit - plain and behind LayerNorm + modulate, 8 and 6 bits, an odd row count."""
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import viditq_amd; from viditq_amd import ops; "
+            "import test_kernels_gpu as t; dev = torch.device('cuda:0'); out = {}\n"
+            "for n_tok, bits in t.SM1_CASES:\n"
+            "    out[(n_tok, bits)] = t._sm1_outputs(ops, dev, n_tok, bits)\n"
+            "torch.save(out, sys.argv[1])\n" % (ROOT, os.path.join(ROOT, "tests")))
+    f = str(tmp_path / "registers.pt")
+    r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, VQ_RQ_SM1="0"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = torch.load(f)
+    assert len(ref) == len(SM1_CASES)
+    for (n_tok, bits), want in ref.items():
+        got = _sm1_outputs(ops, dev, n_tok, bits)
+        assert len(got) == len(want) == 9
+        for i, (g_, w_) in enumerate(zip(got, want)):
+            assert torch.equal(g_, w_), (n_tok, bits, i)
+
+
+def _sm1_outputs(ops, dev, n_tok, bits):
+    C = 1152
+    g = torch.Generator().manual_seed(11 + n_tok)
+    x = h16(1, n_tok, C, scale=2.5, seed=n_tok).to(dev)
+    x[0, 5] = 0                                     # a constant row: eps-fill
+    s = torch.exp(torch.randn(C, generator=g) * 0.7).float().to(dev)
+    shift = h16(1, C, scale=0.3, seed=5).float().to(dev)
+    scale = h16(1, C, scale=0.3, seed=6).float().to(dev)
+    a = ops.rowquant(x, s=s, n_bits=bits)
+    b, xm = ops.ln_modulate_rowquant(x, shift, scale, 1e-6, smooth=[s], n_bits=bits, want_xm=True)
+    return [t_.cpu() for t_ in (a.xq, a.sx, a.zx, a.R, b[0].xq, b[0].sx, b[0].zx, b[0].R, xm)]
+
+
 @pytest.mark.parametrize("n_tok", [131, 4096])
 def test_smoothed_quantizers_for_a_batch_of_two_share_the_grid(ops, dev, n_tok):
     """x [2, n_tok, C] with smoothing (the t2i uncond | cond forward under a smooth-quant plan): the pair kernels

@@ -8,17 +8,27 @@ M = 16384
 g = torch.Generator().manual_seed(0)
 
 
-def timeit(fn, n=200, warm=30):
-    for _ in range(warm):
-        fn()
+def timeit(fn, n=24, reps=12):
+    """GPU time per call: n calls captured into one graph (the Python wrappers cost 10-20 us of host time per call - more than
+    some of these kernels - so back-to-back eager launches measure the host), replayed reps times after a warm replay phase"""
+    fn()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(gr, stream=st):
+            for _ in range(n):
+                fn()
+    for _ in range(20):
+        gr.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(n):
-        fn()
+    for _ in range(reps):
+        gr.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    return e0.elapsed_time(e1) / (n * reps) * 1e3
 
 
 x = torch.randn(1, M, 1152, generator=g).half().to(dev)
@@ -41,6 +51,7 @@ def rot():
 print("rowquant C=1152              %6.1f us (rotating inputs %6.1f)" % (timeit(lambda: ops.rowquant(x)), timeit(lambda: ops.rowquant(rot()))))
 print("LN+mod+quant C=1152          %6.1f us (rotating inputs %6.1f)" % (timeit(lambda: ops.ln_modulate_rowquant(x, sh, sc)), timeit(lambda: ops.ln_modulate_rowquant(rot(), sh, sc))))
 print("rowquant smooth C=1152       %6.1f us" % timeit(lambda: ops.rowquant(rot(), s=sm[0])))
+print("LN+mod+1 smooth C=1152       %6.1f us" % timeit(lambda: ops.ln_modulate_rowquant(rot(), sh, sc, smooth=sm[:1])))
 print("rowquant_multi 3 x C=1152    %6.1f us" % timeit(lambda: ops.rowquant_multi(rot(), sm)))
 print("LN+mod+3 smooth C=1152       %6.1f us" % timeit(lambda: ops.ln_modulate_rowquant(rot(), sh, sc, smooth=sm)))
 print("rowquant C=4608              %6.1f us" % timeit(lambda: ops.rowquant(x4)))

@@ -980,8 +980,32 @@ static bool launch_smooth_half(const half_t* x, const float* shift, const float*
 // conflict-free ds_read_b128 per four channels, both half-waves reading the same words), so one set of row registers
 // serves every output: the row is read once, normalised once, and quantized NOUT times.
 // ---------------------------------------------------------------------------
+// One smoothed output through the same kernel (round 5; VQ_RQ_SM1=0 keeps smooth_rowquant_half_kernel): with the vectors in
+// LDS a wave needs ~80 registers instead of 167 (LN: 248), i.e. every wave of a launch is resident at once.
+#ifndef VQ_SM1_MINW
+#define VQ_SM1_MINW 6
+#endif
+#ifndef VQ_SM1_RPW
+#define VQ_SM1_RPW 1
+#endif
+#ifndef VQ_SM1_NWV
+#define VQ_SM1_NWV 8
+#endif
+#ifndef VQ_SMM_RPW       // the two- / three-output launches: row pairs per wave, waves per workgroup, waves per SIMD asked of the compiler
+#define VQ_SMM_RPW 1
+#endif
+#ifndef VQ_SMM_NWV
+#define VQ_SMM_NWV 8
+#endif
+#ifndef VQ_SMM_MINW
+#define VQ_SMM_MINW 4
+#endif
+static int vq_sm1_mode() {
+    static const int mode = getenv("VQ_RQ_SM1") ? atoi(getenv("VQ_RQ_SM1")) : 1;
+    return mode;
+}
 template <int NIT, bool LN, int NOUT, int RPW, int NWV>
-__global__ __launch_bounds__(64 * NWV, 4) void smooth_rowquant_multi_kernel(
+__global__ __launch_bounds__(64 * NWV, NOUT == 1 ? VQ_SM1_MINW : VQ_SMM_MINW) void smooth_rowquant_multi_kernel(
     const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
     LnqFastOut o, half_t* __restrict__ xm_out, int n_tok, int n_bits, int32_t* status) {
     constexpr int C = 128 * NIT;
@@ -1110,7 +1134,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void smooth_rowquant_multi_kernel(
 template <bool LN, int NOUT>
 static bool launch_smooth_multi(const half_t* x, const float* shift, const float* scale, float eps, const LnqFastOut& o,
                                 half_t* xm, int n_tok, int C, int n_bits, int32_t* status, hipStream_t st) {
-    constexpr int RPW = 2, NWV = 8;
+    constexpr int RPW = NOUT == 1 ? VQ_SM1_RPW : VQ_SMM_RPW, NWV = NOUT == 1 ? VQ_SM1_NWV : VQ_SMM_NWV;
     const size_t lds = (size_t)(2 * NOUT + (LN ? 2 : 0)) * C * sizeof(float);
     dim3 grid((n_tok + 2 * NWV * RPW - 1) / (2 * NWV * RPW));
 #define SMM_GO(N_)                                                                                                   \
@@ -1156,6 +1180,7 @@ bool vq_rowquant_fast(const half_t* x, const half_t* add_rows, int add_div, cons
     if (hs && s_rcp && !ha && !zpf && C % 128 == 0 && Kp == C && C >= 768 && C <= 1280 && n_tok >= 2) {
         LnqFastOut o{};
         o.s[0] = s, o.r[0] = s_rcp, o.xq[0] = xq, o.sx[0] = sx, o.zx[0] = zx, o.R[0] = R;
+        if (vq_sm1_mode() && launch_smooth_multi<false, 1>(x, nullptr, nullptr, 0.f, o, nullptr, n_tok, C, n_bits, status, st)) return true;
         if (launch_smooth_half<false, 2>(x, nullptr, nullptr, 0.f, o, 1, nullptr, n_tok, C, n_bits, status, st)) return true;
     }
     if (!hs && !ha && C % 128 == 0 && Kp == C && (C == 1152 || C == 1024 || C == 1280 || C == 768) && n_tok >= 2) {
@@ -1329,6 +1354,7 @@ bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float 
                 o.s[j] = s[j], o.r[j] = s_rcp[j], o.xq[j] = xq[j], o.sx[j] = sx[j], o.zx[j] = zx[j], o.R[j] = R[j];
             if (n_out == 3 && launch_smooth_multi<true, 3>(x, shift, scale, eps, o, xm, n_tok, C, n_bits, status, st)) return true;
             if (n_out == 2 && launch_smooth_multi<true, 2>(x, shift, scale, eps, o, xm, n_tok, C, n_bits, status, st)) return true;
+            if (n_out == 1 && vq_sm1_mode() && launch_smooth_multi<true, 1>(x, shift, scale, eps, o, xm, n_tok, C, n_bits, status, st)) return true;
             if (launch_smooth_half<true, 4>(x, shift, scale, eps, o, n_out, xm, n_tok, C, n_bits, status, st)) return true;
         }
     }
@@ -1372,5 +1398,6 @@ bool vq_rowquant_smooth_multi_fast(const half_t* x, int n_out, const float* cons
         o.s[j] = s[j], o.r[j] = s_rcp[j], o.xq[j] = xq[j], o.sx[j] = sx[j], o.zx[j] = zx[j], o.R[j] = R[j];
     if (n_out == 3 && launch_smooth_multi<false, 3>(x, nullptr, nullptr, 0.f, o, nullptr, n_tok, C, n_bits, status, st)) return true;
     if (n_out == 2 && launch_smooth_multi<false, 2>(x, nullptr, nullptr, 0.f, o, nullptr, n_tok, C, n_bits, status, st)) return true;
+    if (n_out == 1 && vq_sm1_mode() && launch_smooth_multi<false, 1>(x, nullptr, nullptr, 0.f, o, nullptr, n_tok, C, n_bits, status, st)) return true;
     return launch_smooth_half<false, 2>(x, nullptr, nullptr, 0.f, o, n_out, nullptr, n_tok, C, n_bits, status, st);
 }
