@@ -56,3 +56,5 @@ print("rowquant_multi 3 x C=1152    %6.1f us" % timeit(lambda: ops.rowquant_mult
 print("LN+mod+3 smooth C=1152       %6.1f us" % timeit(lambda: ops.ln_modulate_rowquant(rot(), sh, sc, smooth=sm)))
 print("rowquant C=4608              %6.1f us" % timeit(lambda: ops.rowquant(x4)))
 print("rowquant smooth C=4608       %6.1f us" % timeit(lambda: ops.rowquant(x4, s=sm4)))
+print("GELU + rowquant C=4608       %6.1f us" % timeit(lambda: ops.gelu_rowquant(x4)))
+print("GELU + rowquant smooth 4608  %6.1f us" % timeit(lambda: ops.gelu_rowquant(x4, s=sm4)))
