@@ -507,7 +507,7 @@ def test_smoothed_outputs_of_one_pass_equal_the_per_output_kernels(ops, dev, n_t
             assert torch.equal(xm, xm1)
 
 
-SM1_CASES = ((257, 8), (2048, 6), (16384, 8))
+SM1_CASES = ((257, 8, 1152), (2048, 6, 1152), (16384, 8, 1152), (300, 8, 768), (131, 8, 1024), (515, 6, 1280))
 
 
 def test_single_smoothed_output_with_vectors_in_lds_is_bit_identical_to_the_register_kernel(ops, dev, tmp_path):
@@ -515,13 +515,14 @@ def test_single_smoothed_output_with_vectors_in_lds_is_bit_identical_to_the_regi
     smooth_rowquant_multi_kernel<.., NOUT = 1> - smoothing vectors, reciprocals and modulation vectors in LDS, ~96 registers
     per wave instead of 167 (behind LayerNorm: 248).  Against smooth_rowquant_half_kernel (vectors in registers), selected in
     a child process by VQ_RQ_SM1=0: the same per-lane expressions in the same order, so codes, steps, zero points, row sums
-    and the modulated activation are equal bit for bit - plain and behind LayerNorm + modulate, 8 and 6 bits, an odd row count."""
+    and the modulated activation are equal bit for bit - plain and behind LayerNorm + modulate, 8 and 6 bits, odd row counts,
+    every width the kernels are built for (768, 1024, 1152, 1280)."""
     import subprocess
     import sys
     code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import viditq_amd; from viditq_amd import ops; "
             "import test_kernels_gpu as t; dev = torch.device('cuda:0'); out = {}\n"
-            "for n_tok, bits in t.SM1_CASES:\n"
-            "    out[(n_tok, bits)] = t._sm1_outputs(ops, dev, n_tok, bits)\n"
+            "for n_tok, bits, C in t.SM1_CASES:\n"
+            "    out[(n_tok, bits, C)] = t._sm1_outputs(ops, dev, n_tok, bits, C)\n"
             "torch.save(out, sys.argv[1])\n" % (ROOT, os.path.join(ROOT, "tests")))
     f = str(tmp_path / "registers.pt")
     r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, VQ_RQ_SM1="0"), capture_output=True, text=True,
@@ -529,15 +530,14 @@ def test_single_smoothed_output_with_vectors_in_lds_is_bit_identical_to_the_regi
     assert r.returncode == 0, r.stderr[-2000:]
     ref = torch.load(f)
     assert len(ref) == len(SM1_CASES)
-    for (n_tok, bits), want in ref.items():
-        got = _sm1_outputs(ops, dev, n_tok, bits)
+    for (n_tok, bits, C), want in ref.items():
+        got = _sm1_outputs(ops, dev, n_tok, bits, C)
         assert len(got) == len(want) == 9
         for i, (g_, w_) in enumerate(zip(got, want)):
-            assert torch.equal(g_, w_), (n_tok, bits, i)
+            assert torch.equal(g_, w_), (n_tok, bits, C, i)
 
 
-def _sm1_outputs(ops, dev, n_tok, bits):
-    C = 1152
+def _sm1_outputs(ops, dev, n_tok, bits, C):
     g = torch.Generator().manual_seed(11 + n_tok)
     x = h16(1, n_tok, C, scale=2.5, seed=n_tok).to(dev)
     x[0, 5] = 0                                     # a constant row: eps-fill
