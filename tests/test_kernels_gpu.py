@@ -507,6 +507,29 @@ def test_smoothed_outputs_of_one_pass_equal_the_per_output_kernels(ops, dev, n_t
             assert torch.equal(xm, xm1)
 
 
+@pytest.mark.parametrize("n_tok,C", [(4096, 1152), (131, 1152), (300, 768)])
+def test_ln_modulate_pair_kernel_also_writes_the_modulated_activation(ops, dev, n_tok, C):
+    """B = 2 with want_xm (the t2i final layer: LayerNorm + modulate in front of a Linear that quantizes its own input) runs
+    the pair kernel too (round 5; the generic kernel took 74 us per PixArt-Sigma step): its codes / steps / zero points / row
+    sums are bit-identical to the same launch without the fp16 output, and the fp16 output equals each sample's B = 1 launch
+    up to the last fp16 ulp on < 0.5 % of the elements (the two sum a row in different orders)."""
+    x = h16(2, n_tok, C, scale=2.5, seed=n_tok + C).to(dev)
+    shift = h16(2, C, scale=0.3, seed=5).float().to(dev)
+    scale = h16(2, C, scale=0.3, seed=6).float().to(dev)
+    a = ops.ln_modulate_rowquant(x, shift, scale, 1e-6)[0]
+    b, xm = ops.ln_modulate_rowquant(x, shift, scale, 1e-6, want_xm=True)
+    for f in ("xq", "sx", "zx", "R"):
+        assert torch.equal(getattr(a, f), getattr(b[0], f)), f
+    assert xm.shape == x.shape and xm.dtype == torch.float16
+    for smp in range(2):
+        _, x1 = ops.ln_modulate_rowquant(x[smp:smp + 1].contiguous(), shift[smp:smp + 1].contiguous(),
+                                         scale[smp:smp + 1].contiguous(), 1e-6, want_xm=True)
+        d = (xm[smp].float() - x1[0].float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 and float((xm[smp] != x1[0]).float().mean()) < 5e-3
+    ref = torch.nn.functional.layer_norm(x.float(), (C,), eps=1e-6) * (1 + scale[:, None]) + shift[:, None]
+    assert rel_l2(xm.float().cpu(), ref.cpu()) < 1e-3
+
+
 SM1_CASES = ((257, 8, 1152), (2048, 6, 1152), (16384, 8, 1152), (300, 8, 768), (131, 8, 1024), (515, 6, 1280))
 
 

@@ -25,7 +25,7 @@ bool vq_rowquant_pair_smooth_fast(const half_t* x, const float* s, const float* 
                                   int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
 bool vq_lnq_pair_fast(const half_t* x, const float* shift, const float* scale, float eps, const float* s, const float* s_rcp,
                       int8_t* xq, float* sx,
-                      int32_t* zx, int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
+                      int32_t* zx, int32_t* R, half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st);
 bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float eps, int n_out,
                  const float* const* s, const float* const* s_rcp, int8_t* const* xq, float* const* sx,
                  int32_t* const* zx, int32_t* const* R, half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status,
@@ -492,9 +492,9 @@ extern "C" int vq_ln_modulate_rowquant(const void* x, const float* shift, const 
     if (B == 1 && vq_lnq_fast((const half_t*)x, shift, scale, ln_eps, n_out, s, s_rcp, xq, sx, zx, R, (half_t*)xm_out, n_tok,
                               C, Kp, n_bits, status, (hipStream_t)stream))
         return vq_check_launch();
-    if (B == 2 && n_out == 1 && !xm_out &&
+    if (B == 2 && n_out == 1 &&
         vq_lnq_pair_fast((const half_t*)x, shift, scale, ln_eps, s ? s[0] : nullptr, (s && s[0] && s_rcp) ? s_rcp[0] : nullptr,
-                         xq[0], sx[0], zx[0], R[0], n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
+                         xq[0], sx[0], zx[0], R[0], (half_t*)xm_out, n_tok, C, Kp, n_bits, status, (hipStream_t)stream))
         return vq_check_launch();
     LnqOut o;
     for (int j = 0; j < 3; ++j) {

@@ -722,11 +722,13 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_fast_kernel(
         const T_ r3_ = __builtin_bit_cast(T_, __builtin_amdgcn_readlane(b_, 48));                       \
         v_ = hi ? OP_(r2_, r3_) : OP_(r0_, r1_);                                                        \
     }
-template <int NIT, bool PAIR = false>   // PAIR: see rowquant_half_kernel; shift / scale [2, C], one row per sample
+// XM: also store the modulated activation as fp16 (the t2i final layer's LayerNorm + modulate in front of a Linear that
+// quantizes its own input: for B = 2 that call used to fall to the generic kernel, 74 us per PixArt-Sigma step)
+template <int NIT, bool PAIR = false, bool XM = false>   // PAIR: see rowquant_half_kernel; shift / scale [2, C], one row per sample
 __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
     const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
     int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R, int n_tok,
-    int n_bits, int32_t* status) {
+    int n_bits, int32_t* status, half_t* __restrict__ xm = nullptr) {
     constexpr int C = 128 * NIT;
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const bool hi = lane >= 32;
@@ -781,6 +783,12 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
             v[i][e] = u;
             vmin = fminf(vmin, u);
             vmax = fmaxf(vmax, u);
+        }
+        if constexpr (XM) {
+            if (live) {
+                const half4 hm = {(half_t)v[i][0], (half_t)v[i][1], (half_t)v[i][2], (half_t)v[i][3]};
+                *reinterpret_cast<half4*>(xm + (size_t)tok * C + hl * 4 + i * 128) = hm;
+            }
         }
     }
     RQH_REDUCE2(float, fminf, vmin)
@@ -1243,18 +1251,22 @@ bool vq_rowquant_pair_smooth_fast(const half_t* x, const float* s, const float* 
 
 bool vq_lnq_pair_fast(const half_t* x, const float* shift, const float* scale, float eps, const float* s, const float* s_rcp,
                       int8_t* xq, float* sx,
-                      int32_t* zx, int32_t* R, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
+                      int32_t* zx, int32_t* R, half_t* xm, int n_tok, int C, int Kp, int n_bits, int32_t* status, hipStream_t st) {
     if (Kp != C || !(C == 1152 || C == 1024 || C == 1280 || C == 768)) return false;
     if (s) {
-        if (!s_rcp) return false;
+        if (!s_rcp || xm) return false;
         LnqFastOut o{};
         o.s[0] = s, o.r[0] = s_rcp, o.xq[0] = xq, o.sx[0] = sx, o.zx[0] = zx, o.R[0] = R;
         return launch_smooth_half<true, 2, true>(x, shift, scale, eps, o, 1, nullptr, n_tok, C, n_bits, status, st);
     }
     dim3 g2((n_tok + RQF_WAVES - 1) / RQF_WAVES);
 #define LNP_GO(N_)                                                                                                    \
-    hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, true>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
-                       xq, sx, zx, R, n_tok, n_bits, status)
+    if (xm)                                                                                                           \
+        hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, true, true>), g2, dim3(RQF_THREADS), 0, st, x, shift,   \
+                           scale, eps, xq, sx, zx, R, n_tok, n_bits, status, xm);                                     \
+    else                                                                                                              \
+        hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, true>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
+                           xq, sx, zx, R, n_tok, n_bits, status, (half_t*)nullptr)
     switch (C / 128) {
         case 6: LNP_GO(6); break;
         case 8: LNP_GO(8); break;
