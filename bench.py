@@ -145,8 +145,13 @@ def _rocm_smi(index):
 
 
 class Telemetry:
-    """snapshot(): one reading; start() / stop(): a 20 Hz sysfs sampler thread around a timed region (sysfs only: a
-    rocm-smi process per sample would perturb what it measures)."""
+    """snapshot(): one full reading (power, clocks, temperature, the fabric / SoC / memory DPM tables); start() / stop(): a
+    sampler thread around a timed region that reads ONLY board power and shader clock (two hwmon files) five times a second -
+    round-5 advisor: the full set at 20 Hz cost ~250 ms per sample on the driver's box (SMU metric queries behind the pp_dpm
+    tables), i.e. the headline was timed with SMU traffic and a Python thread beside it.  Temperature and the DPM tables come
+    from the snapshots before and after the region.  (sysfs only: a rocm-smi process per sample would perturb what it
+    measures.)  A/B of this sampler against --no-telemetry on one box: profiles/r06_experiments.md."""
+    LIGHT = ("power_w", "sclk_mhz")
 
     def __init__(self, index):
         self.index = index
@@ -158,7 +163,9 @@ class Telemetry:
     def snapshot(self):
         return _read_sysfs(self.files) if self.files else _rocm_smi(self.index)
 
-    def start(self):
+    def start(self, resume=False):
+        """resume: keep the rows of earlier start / stop pairs (several prompts: one sampled region per prompt's TIMED loop,
+        the untimed graph captures between them are not sampled)"""
         import threading
         if not self.files:
             # no sysfs sensor for this device: ONE rocm-smi reading taken while the timed region runs (the process start
@@ -167,13 +174,16 @@ class Telemetry:
             self._th = threading.Thread(target=lambda: self._one.update(_rocm_smi(self.index)), daemon=True)
             self._th.start()
             return
-        self._rows = []
+        if not resume:
+            self._rows = []
         self._stop = threading.Event()
+
+        light = {k: v for k, v in self.files.items() if k in self.LIGHT} or self.files
 
         def run():
             while not self._stop.is_set():
-                self._rows.append(_read_sysfs(self.files))
-                self._stop.wait(0.05)
+                self._rows.append(_read_sysfs(light))
+                self._stop.wait(0.2)
         self._th = threading.Thread(target=run, daemon=True)
         self._th.start()
 
@@ -541,9 +551,10 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
         if dist is not None and n_done == 0:
             dist.barrier()
         torch.cuda.synchronize()
-        if TEL is not None and n_done == 0:
-            tel_before = TEL.snapshot()
-            TEL.start()
+        if TEL is not None:
+            if n_done == 0:
+                tel_before = TEL.snapshot()
+            TEL.start(resume=n_done > 0)
         t0 = time.perf_counter()
         for j in range(warmup, warmup + steps):
             x, buf = step(j, x, buf)
@@ -554,8 +565,24 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
             torch.cuda.synchronize()
         el += time.perf_counter() - t0
         host_enqueue += t_enq
-        if TEL is not None and n_done == len(mine) - 1:
-            res["telemetry"] = leg_telemetry(TEL, tel_before, TEL.stop(), dev)
+        if gs is not None and n_done == len(mine) - 1:
+            # What a replay costs the HOST, measured with an EMPTY queue (a synchronize before every launch).  The figure above
+            # (host_enqueue_ms_per_step) is the time until the loop's last replay call returned: with more than ~7 steps in
+            # flight hipGraphLaunch blocks on the full hardware queue, so over 20 steps it reads ~GPU time per step
+            # (25-27 ms of a 38 ms step) while over 6 steps it reads 3.5 ms - back-pressure, not launch cost.
+            idle = []
+            for j in range(warmup + steps, warmup + steps + 4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                x, buf = step(j, x, buf)
+                idle.append(time.perf_counter() - t1)
+            torch.cuda.synchronize()
+            res["host_graph_launch_ms_idle_queue"] = sorted(idle)[len(idle) // 2] * 1e3
+            res["graph_nodes"] = graph_census(gs)
+        if TEL is not None:
+            during = TEL.stop()                         # aggregated over the timed loops of every prompt so far
+            if n_done == len(mine) - 1:
+                res["telemetry"] = leg_telemetry(TEL, tel_before, during, dev)
         if n_done < len(mine) - 1:
             gs = None                                   # frees this prompt's graphs before the next capture
     assert torch.isfinite(x).all()
@@ -596,6 +623,32 @@ def _measure_plan(a, dev, rank, world, qnn, cfg, plan, steps, warmup, dist, even
            host_enqueue_ms_per_step=host_enqueue / (steps * len(mine)) * 1e3,
            roofline=gemm_roofline(timing, el / len(mine), plan == "w8a8") if timing else None)
     return res
+
+
+def graph_census(gs):
+    """Node counts of the captured step graphs by kind (VQ_GRAPH_DUMP=<prefix>: graph.StepGraph writes the runtime's .dot
+    dump of each capture); None without the dump."""
+    out = None
+    for g in getattr(gs, "graphs", {}).values():
+        if out is None and getattr(g, "c_abi_calls", None):
+            out = {"c_abi_calls_per_step": g.c_abi_calls,
+                   "note": "entry points of libviditq_hip.so recorded into one step graph (cond + uncond), one kernel node each; "
+                           "torch's own elementwise kernels of the FP edges (~60 per step) come on top"}
+        path = getattr(g, "dot_path", None)
+        if not path or not os.path.exists(path):
+            continue
+        txt = open(path, errors="replace").read()
+        nodes = [ln for ln in txt.splitlines() if "label=" in ln and "->" not in ln]
+        c = {"nodes": len(nodes), "edges": txt.count("->")}
+        for kind in ("KERNEL", "MEMCPY", "MEMSET", "EMPTY", "EVENT", "HOST"):
+            c[kind.lower()] = sum(1 for ln in nodes if kind in ln.upper())
+        if out is None or "nodes" not in out:
+            out = dict(out or {}, **c)
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return out
 
 
 def pixart_leg(dev, steps=10, w_bits=4, size=1024, Lp=300, warmup=3):
@@ -815,6 +868,10 @@ def main():
                 # timed region; the clock the GEMM itself ran at right after it) and how far ahead of the GPU the host was
                 "telemetry": head.get("telemetry"),
                 "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+                # (the figure above includes the time hipGraphLaunch waits on a FULL hardware queue once the host is ~7 steps
+                #  ahead; the one below is a replay launched into an empty queue - the host's own cost per step)
+                "host_graph_launch_ms_idle_queue": head.get("host_graph_launch_ms_idle_queue"),
+                "graph_nodes": head.get("graph_nodes"),
                 "extras": extras}
         if rehearsal:
             line["rehearsal"] = "ranks share devices, gloo backend: control-flow dry run, NOT a measurement"

@@ -177,11 +177,12 @@ int vq_weight_minmax(const void* W, const float* s, float* delta, float* zp,
  * xq [M,Kp] int8, wq [N,Kp] int8 (w_bits>4) or [N,Kp/2] nibbles (w_bits<=4)
  * bias nullable [N] fp32; out [M, ldo] fp16 written at columns [0,N)
  * resid nullable [M, ldo] fp16; gate nullable fp32 [M/rows_per_gate, N]
- * variant: VQ_GEMM_DEFAULT (tile form chosen by shape), or a pinned form of the same kernel - 11: 256 x 288 tile, 8 waves;
- * 16: 128 x 288 tile; 18: 256 x 288 tile, 12 waves (interior tiles only: M % 256 == 0, N % 288 == 0, ldo % 8 == 0,
- * rows_per_gate % 256 == 0, else VQ_ESHAPE); 19: 256 x 288 tile, 8 waves, interior form (scalar-addressed stage pieces,
- * one wave per SIMD issues them; M % 256 == 0 and N % 288 == 0, else VQ_ESHAPE) - what VQ_GEMM_DEFAULT picks for such
- * shapes.  All forms give bit-identical results.
+ * variant: VQ_GEMM_DEFAULT (form chosen by shape), or a pinned form of the same kernel -
+ *   11: 256 x 288 tile, 8 waves, general form (any M, N);  16: 128 x 288 tile, general form;
+ *   19: 256 x 288 tile, interior form (scalar-addressed stage pieces, one wave per SIMD issues them) - what
+ *       VQ_GEMM_DEFAULT picks for launches made of interior tiles;
+ *   19 returns VQ_ESHAPE unless M % 256 == 0, N % 288 == 0, ldo % 8 == 0 and - VQ_EPI_GATE_RESID - rows_per_gate % 256
+ *   == 0 (VQ_GEMM_DEFAULT falls back to the general form instead).  All forms give bit-identical results.
  */
 int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R,
                const void* wq, const float* sw, const int32_t* zw, const int32_t* cs,

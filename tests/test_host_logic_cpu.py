@@ -404,6 +404,12 @@ def test_fp_edge_and_gelu_one_pass_routing_decisions():
     # (round 5: the smoothed pair no longer depends on row length or on the vector having a reciprocal - the register
     #  pair kernel divides exactly when ops.smooth_rcp(s) is None)
     assert fc2.gelu_one_pass_ok(2, 1152, s) and not fc2.gelu_one_pass_ok(3, 4608, None)
+    # what the one-pass kernel itself refuses is refused HERE, before the producing GEMM's epilogue is chosen (round-5
+    # advisor): rows longer than 4608 padded channels, rows that are not whole 16-byte chunks
+    for B in (1, 2):
+        assert not fc2.gelu_one_pass_ok(B, 6144, None) and not fc2.gelu_one_pass_ok(B, 6144, torch.ones(6144))
+        assert not fc2.gelu_one_pass_ok(B, 1156, None)
+        assert fc2.gelu_one_pass_ok(B, 4608, None) and fc2.gelu_one_pass_ok(B, 4600, None)
 
 
 def test_seeded_inputs_and_weights_reproduce_their_recorded_checksums():

@@ -288,33 +288,6 @@ def test_gemm_half_height_tile_is_bit_identical(ops, dev, M, N, K, w_bits):
 
 
 @pytest.mark.parametrize("w_bits", [8, 4])
-@pytest.mark.parametrize("M,N,K", [(512, 576, 256), (1024, 1152, 1152), (768, 4608, 1152), (512, 1152, 4608), (256, 288, 128)])
-def test_gemm_twelve_wave_form_is_bit_identical(ops, dev, M, N, K, w_bits):
-    """The 12-wave form of the ring kernel (variant 18: 4 x 3 waves of 64 x 96, epilogue through half slabs; what the library
-    picks for the long launches, fc1 / fc2) computes every output with the arithmetic of the 8-wave form (variant 11): equal
-    bit for bit, every epilogue, W8 and W4, odd and even k-tile counts; shapes that are not made of interior tiles are
-    refused for the pinned variant and take the 8-wave form by default."""
-    x = h16(1, M, K, scale=1.5, seed=M + K).to(dev)
-    W = h16(N, K, scale=0.04, seed=N).to(dev)
-    b = h16(N, scale=0.1, seed=5).float().to(dev)
-    resid = h16(M, N, scale=1.0, seed=6).to(dev)
-    gate = h16(M // 256, N, scale=0.5, seed=7).float().to(dev)
-    qa = ops.rowquant(x)
-    d, z = ops.weight_minmax(W, w_bits)
-    pw = ops.pack_weight(W, d, z, w_bits)
-    for kw in (dict(epilogue=ops.EPI_NONE), dict(epilogue=ops.EPI_GELU), dict(epilogue=ops.EPI_RESID, resid=resid),
-               dict(epilogue=ops.EPI_GATE_RESID, resid=resid, gate=gate, rows_per_gate=256)):
-        o11 = ops.gemm_i8(qa, pw, bias=b, variant=11, **kw)
-        o18 = ops.gemm_i8(qa, pw, bias=b, variant=18, **kw)
-        assert torch.equal(o11, o18), kw["epilogue"]
-        assert torch.equal(ops.gemm_i8(qa, pw, bias=b, **kw), o11)
-    qr = ops.rowquant(h16(1, 300, K, scale=1.5, seed=1).to(dev))          # ragged: not interior
-    with pytest.raises(Exception):
-        ops.gemm_i8(qr, pw, bias=b, variant=18)
-    assert torch.equal(ops.gemm_i8(qr, pw, bias=b), ops.gemm_i8(qr, pw, bias=b, variant=11))
-
-
-@pytest.mark.parametrize("w_bits", [8, 4])
 @pytest.mark.parametrize("M,N,K", [(512, 576, 256), (1024, 1152, 1152), (768, 4608, 1152), (512, 1152, 4608), (256, 288, 128),
                                    (16384, 1152, 1152), (8192, 1152, 1152)])
 def test_gemm_interior_form_is_bit_identical(ops, dev, M, N, K, w_bits):
@@ -1028,6 +1001,25 @@ def test_gemm_i8_batched_equals_separate_launches(ops, dev):
         assert torch.equal(got[b], outs[b])
 
 
+@pytest.mark.parametrize("M", [256, 1024])
+def test_gemm_i8_batched_interior_shape_equals_general_form_launches(ops, dev, M):
+    """A batched launch made of interior tiles takes the interior form of the kernel (256 rows: 128-row tiles, 1024 rows:
+    256-row tiles by the library's tile-height rule) with a weight set per tile: bit-identical to one general-form launch
+    (variant 11) per weight set."""
+    N, K, nb = 1152, 1152, 3
+    qa = ops.rowquant(h16(1, M, K, scale=1.0, seed=3).to(dev))
+    pws, biases, outs = [], [], []
+    for b in range(nb):
+        W = h16(N, K, scale=0.04, seed=10 + b).to(dev)
+        d, z = ops.weight_minmax(W, 8)
+        pws.append(ops.pack_weight(W, d, z, 8))
+        biases.append(h16(N, scale=0.1, seed=20 + b).float().to(dev))
+        outs.append(ops.gemm_i8(qa, pws[-1], bias=biases[-1], variant=11))
+    got = ops.gemm_i8_batched(qa, ops.stack_packed(pws, biases))
+    for b in range(nb):
+        assert torch.equal(got[b], outs[b])
+
+
 @pytest.mark.parametrize("w_bits", [8, 4])
 @pytest.mark.parametrize("N,K", [(1152, 1152), (4608, 1152), (1152, 4608)])
 def test_gemm_full_size_against_the_library_integer_matmul(ops, dev, N, K, w_bits):
@@ -1133,11 +1125,12 @@ def test_gemm_fp_dequant_under_adversarial_cancellation(ops, dev, w_bits):
 
 
 @pytest.mark.parametrize("w_bits", [8, 4])
-@pytest.mark.parametrize("M,G", [(600, 3), (1024, 2), (77, 3)])
+@pytest.mark.parametrize("M,G", [(600, 3), (1024, 2), (77, 3), (16384, 3), (8192, 3)])
 def test_gemm_i8_grouped_equals_separate_launches(ops, dev, w_bits, M, G):
     """vq_gemm_i8_grouped: the q / k / v Linears of a plan with one smoothing vector per Linear (three quantized copies
-    of the input, three weights) in one grid - bit-identical to one vq_gemm_i8 launch per Linear into the same
-    column block, ragged token tiles included."""
+    of the input, three weights) in one grid - bit-identical to one GENERAL-form vq_gemm_i8 launch (variant 11) per Linear
+    into the same column block, ragged token tiles included; at 16384 / 8192 tokens the grouped launch is made of interior
+    tiles (256- / 128-row) and takes the interior form (three rounds of the CUs)."""
     N, K = 1152, 1152
     x = h16(1, M, K, scale=1.5, seed=M).to(dev)
     g = torch.Generator().manual_seed(5)
@@ -1151,7 +1144,7 @@ def test_gemm_i8_grouped_equals_separate_launches(ops, dev, w_bits, M, G):
         biases.append(h16(N, scale=0.1, seed=40 + j).float().to(dev) if j != 1 else None)
     ref = torch.zeros((M, 3 * N), dtype=torch.float16, device=dev)
     for j in range(G):
-        ops.gemm_i8(acts[j], pws[j], bias=biases[j], out=ref[:, j * N:(j + 1) * N])
+        ops.gemm_i8(acts[j], pws[j], bias=biases[j], out=ref[:, j * N:(j + 1) * N], variant=11)
     got = torch.zeros((M, 3 * N), dtype=torch.float16, device=dev)
     ops.gemm_i8_grouped(acts, pws, biases, out=got)
     assert torch.equal(got, ref)
@@ -1260,5 +1253,17 @@ def test_fp_edge_linear_keeps_the_module_path_for_autograd_and_hooks(ops, dev):
     with torch.no_grad():
         assert fp_edge_linear(lin, x) is None                          # a hook would not fire: module path
     h.remove()
+    with torch.no_grad():
+        assert fp_edge_linear(lin, x) is not None
+    # hooks registered for every module (observer / calibration tooling) and backward hooks on the layer keep the module
+    # path too (round-5 advisor)
+    gh = torch.nn.modules.module.register_module_forward_hook(lambda m, i, o: None)
+    with torch.no_grad():
+        assert fp_edge_linear(lin, x) is None
+    gh.remove()
+    bh = lin.register_full_backward_hook(lambda m, gi, go: None)
+    with torch.no_grad():
+        assert fp_edge_linear(lin, x) is None
+    bh.remove()
     with torch.no_grad():
         assert fp_edge_linear(lin, x) is not None

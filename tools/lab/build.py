@@ -6,9 +6,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libviditq_lab.so")
-SOURCES = ["gemm_lab.hip", "probe.hip", "gemm_4w.hip", "gemm_loader.hip", "gemm_sp.hip"]
+SOURCES = ["gemm_lab.hip", "probe.hip", "gemm_4w.hip", "gemm_loader.hip", "gemm_sp.hip", "gemm_persist6.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm",
-         "-amdgpu-mfma-vgpr-form", "-I", os.path.join(HERE, "..", "..", "vidit-q_amd", "csrc")]
+         "-amdgpu-mfma-vgpr-form", "-I", HERE, "-I", os.path.join(HERE, "..", "..", "vidit-q_amd", "csrc")]
 
 
 def build(force=False):

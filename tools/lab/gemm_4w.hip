@@ -4,7 +4,7 @@
 // the round-3 review: ds_read_b128 per MFMA drop from 13 / 36 to 17 / 72 - does the main loop gain what the fragment
 // reads cost the 8-wave form?  variant: 0 plain, 1 staggered DMA issue (waves 2, 3 later), 10x ablations (results
 // wrong): 101 no LDS-DMA after the prologue, 102 no MFMA, 108 no fragment reads, 109 neither DMA nor reads, 116 stamps.
-#include "gemm_wide.h"
+#include "gemm_wide_lab.h"
 
 template <int EPI, bool STAGGER, int ABL>
 static int launch_4w(const GemmArgs& a, hipStream_t st) {

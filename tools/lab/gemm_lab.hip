@@ -5,7 +5,7 @@
 //   13/15 ping-pong SIMD partners                  14    persistent ring with next-tile prefetch
 //   20/21 half-CU workgroups                       100+  ablations / cycle stamps of the shipping kernel (variant 11)
 // What each one taught is in DESIGN.md (5).  The shipping kernels live in vidit-q_amd/csrc/gemm_i8.hip.
-#include "../../vidit-q_amd/csrc/gemm_wide.h"
+#include "gemm_wide_lab.h"
 #include "gemm_pp.h"
 #include "gemm_half.h"
 

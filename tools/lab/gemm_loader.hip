@@ -13,7 +13,7 @@
 //           68 pieces of a stage and their SIMD partners 4-7 none - the closest a 240-register kernel gets to a loader role.
 // Both address a piece as (lane offset of the piece's parity) + (scalar row/k offset), so a wave holds ONE offset VGPR instead
 // of one per piece.  variant: 0 plain, 101 no DMA after the prologue, 102 no MFMA, 108 no fragment reads, 116 stamps.
-#include "gemm_wide.h"
+#include "gemm_wide_lab.h"
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NL, int EPI, int ABL>
 __global__ __launch_bounds__(64 * (WAVES_M* WAVES_N + NL)) void gemm_i8_loader_kernel(GemmArgs a) {

@@ -11,7 +11,7 @@
 // 8-bit weights, interior tiles, K >= 1152 (nine stages: eight carry the previous tile's stores), epilogues none / resid /
 // gate*y + resid (gate folded).  Dequantisation = ring_dequant<true> (gemm_common.h), residual add = packed fp16: bit-identical
 // to the product kernel (checked by tools/gemm_sp.py).
-#include "gemm_wide.h"
+#include "gemm_wide_lab.h"
 
 namespace sp {
 constexpr int BM = 256, BN = 192, WAVES_N = 2, NW = 8;

@@ -1,4 +1,6 @@
-// gemm_wide.h - the full-line ring kernel (256 x 288 tile, 8 waves of 64 x 144; 128 x 288 with 32 x 144 wave tiles for
+// gemm_wide_r6.h - round-6 lab copy of the product header WITH the persistent form (INT 2: measured, bit-identical, not faster -
+// profiles/r06_experiments.md 5; instantiated by tools/lab/gemm_persist6.hip, never by the product library).
+// the full-line ring kernel (256 x 288 tile, 8 waves of 64 x 144; 128 x 288 with 32 x 144 wave tiles for
 // launches that would otherwise leave half the CUs without a workgroup); see csrc/gemm_i8.hip for the design notes.
 // Product forms only (round 6): the measurement arms of rounds 1-5 (main-loop ablations, issuer / prefetch-distance / slab
 // switches, the twelve-wave tile) live in tools/lab/gemm_wide_lab.h and are compiled into tools/lab/libviditq_lab.so.
@@ -24,27 +26,37 @@
 //        / k offset in the buffer instruction's soffset - 2 VGPRs instead of 9; waves 0 .. NW/2-1 (one per SIMD) issue
 //        EVERY piece of a stage right behind the stage barrier, their SIMD partners none; the kernel carries only the
 //        interior epilogue (197 VGPRs for every epilogue kind).  Bit-identical to INT 0 (tested).
-// (Round 6 measured the interior form as PERSISTENT workgroups with the next tile's first stage requested before the epilogue:
-//  bit-identical, the saved prologues are paid back by the half-slab epilogue it needs - tools/lab/gemm_wide_r6.h,
-//  profiles/r06_experiments.md 5.)
+// INT 2 (round 6): INT 1 as a PERSISTENT workgroup - one workgroup per CU walks tiles vb, vb + grid, ... of the same
+//        XCD-aware order.  The epilogue runs through HALF slabs (76 KiB + parameters at the bottom of LDS), stage 0 lives
+//        at the TOP of LDS (86 .. 152 KiB), stage 1 at the bottom: after the barrier that ends a tile's main loop the
+//        issuing waves request stage 0 of the NEXT tile, which lands while the tile is dequantised and stored; the next
+//        tile starts behind one barrier (a counted vmcnt leaves the epilogue's stores in flight) instead of a cold
+//        prologue.  Same stages, fragment reads, MFMA order and epilogue arithmetic: bit-identical to INT 1 (tested).
 // STAMP: cycle-counter stamps of every wave -> a.gate reinterpreted as long long[tiles][waves][10] (0-6 shader cycles,
-//        7/8 100 MHz wall clock at start/end, 9 arrival at the stage barrier of k-tile 1) - bench telemetry (clock_probe.hip: vq_gemm_i8_stamped).
+//        7/8 100 MHz wall clock at start/end, 9 arrival at the stage barrier of k-tile 1) - bench telemetry (clock_probe.hip: vq_gemm_i8_stamped), INT 0 / 1 only.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool W4>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool W4, int INT>
 struct WideCfg {
     static constexpr int NW = WAVES_M * WAVES_N;
+    static constexpr bool PERSIST = INT == 2;
     static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     static constexpr int WROW = W4 ? 64 : 128;                 // bytes per weight row and stage
     static constexpr int STAGE = BM * 128 + BN * WROW;
-    static constexpr int EPIL = NW * WTM * (WTN * 2 + 16) + 16 * BN + 12 * BM;   // epilogue slabs + parameter blocks
-    static constexpr int LDS = 2 * STAGE > EPIL ? 2 * STAGE : EPIL;
+    static constexpr int SROWS = PERSIST ? WTM / 2 : 0;        // epilogue slab rows per wave (0 = the whole wave tile)
+    static constexpr int SLROWS = SROWS ? SROWS : WTM;
+    static constexpr int EPIL = NW * SLROWS * (WTN * 2 + 16) + 16 * BN + 12 * BM;   // slabs + parameter blocks
+    // persistent form: [slabs | parameters] at the bottom (over stage 1), stage 0 above them
+    static constexpr int A_OFF = PERSIST ? ((EPIL + 1023) / 1024) * 1024 : 0;
+    static constexpr int LDS = PERSIST ? A_OFF + STAGE : (2 * STAGE > EPIL ? 2 * STAGE : EPIL);
     static_assert(LDS <= 163840, "LDS budget of one CU");
+    static_assert(!PERSIST || EPIL <= A_OFF, "stage 0 of the next tile must not overlap the epilogue's slabs");
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4, bool STAMP = false, int INT = 0>
-__device__ __forceinline__ void gemm_i8_wide_tile(const GemmArgs a0, const int vb, const int tid_) {
-    using Cfg = WideCfg<BM, BN, WAVES_M, WAVES_N, W4>;
+__device__ __forceinline__ void gemm_i8_wide_tiles(const GemmArgs a0, const int vb_first, const int vb_step, const int tid_) {
+    using Cfg = WideCfg<BM, BN, WAVES_M, WAVES_N, W4, INT>;
     constexpr int NW = Cfg::NW;
+    constexpr bool PERSIST = Cfg::PERSIST;
     constexpr bool ASYM = INT != 0;                   // one issuing wave per SIMD
     constexpr int NI = ASYM ? NW / 2 : NW;            // issuing waves
     constexpr int WTM = Cfg::WTM, WTN = Cfg::WTN;
@@ -56,19 +68,23 @@ __device__ __forceinline__ void gemm_i8_wide_tile(const GemmArgs a0, const int v
     constexpr int PPW = (PIECES + NI - 1) / NI;
     constexpr int PLAST = PIECES - (PPW - 1) * NI;
     static_assert(INT == 0 || (NI % 2 == 0 && XP % 2 == 0), "one piece parity per issuing wave");
+    static_assert(!(STAMP && PERSIST), "stamps exist for the one-tile forms");
     // weight-fragment ring of three: reads run two channel groups ahead of their MFMAs (3 / 4 / 5 ahead measured flat, round 5)
     constexpr int WPF = 2, WR = 3;
     static_assert((2 * TN) % WR == 0 && WPF < TN, "ring index must repeat per stage");
     constexpr int BARJ = TN - WPF;                    // after the last fragment read of the current stage
     constexpr int DMA_B = TN >= 6 ? 3 : 0;            // late DMA issue point of the staggered half (general form)
     static_assert((TM == 8 || TM == 4 || TM == 2) && TN >= 3 && TN % 3 == 0, "fragment rings below");
+    constexpr int SROWS = Cfg::SROWS, SLROWS = Cfg::SLROWS;
     static_assert(BN * WROW % 1024 == 0 && STAGE % 128 == 0, "whole pieces, 128-byte aligned stages");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "swizzle phase is taken from the fragment row");
+    // stage s of the ring: s * STAGE, or (persistent) stage 0 above the epilogue region and stage 1 at the bottom
+    auto sbase = [](int s) { return PERSIST ? (s ? 0 : Cfg::A_OFF) : s * STAGE; };
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     long long* ts = nullptr;
     if constexpr (STAMP) {
-        ts = reinterpret_cast<long long*>(const_cast<float*>(a0.gate)) + ((size_t)vb * NW + (tid_ >> 6)) * 10;
+        ts = reinterpret_cast<long long*>(const_cast<float*>(a0.gate)) + ((size_t)vb_first * NW + (tid_ >> 6)) * 10;
         ts[7] = wall_clock64();
         ts[0] = __builtin_readcyclecounter();
     }
@@ -146,7 +162,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(const GemmArgs a0, const int v
         for (int i = 0; i < PPW; ++i) {
             const int p = wave + i * NI;
             if (PIECES % NI == 0 || p < PIECES) {
-                const unsigned dst = lds0 + stage * STAGE + p * 1024;
+                const unsigned dst = lds0 + sbase(stage) + p * 1024;
                 if constexpr (INT != 0) {
                     if (p < XP) {
                         const unsigned so = (unsigned)(t.m0 + p * 8) * (unsigned)a0.Kp + kt * 128;
@@ -180,10 +196,10 @@ __device__ __forceinline__ void gemm_i8_wide_tile(const GemmArgs a0, const int v
     const int xf1 = xf0 ^ 64, wf1 = wf0 ^ (W4 ? 32 : 64);
     using WRaw = typename std::conditional<W4, int2v, int4v>::type;
     auto ldx = [&](int stage, int h, int i) {
-        return *reinterpret_cast<const int4v*>(smem + stage * STAGE + (h ? xf1 : xf0) + i * 16 * 128);
+        return *reinterpret_cast<const int4v*>(smem + sbase(stage) + (h ? xf1 : xf0) + i * 16 * 128);
     };
     auto ldw = [&](int stage, int h, int j) {
-        return *reinterpret_cast<const WRaw*>(smem + stage * STAGE + (h ? wf1 : wf0) + j * 16 * WROW);
+        return *reinterpret_cast<const WRaw*>(smem + sbase(stage) + (h ? wf1 : wf0) + j * 16 * WROW);
     };
     auto wop = [&](const WRaw& r) -> int4v {
         if constexpr (W4) {
@@ -197,7 +213,7 @@ __device__ __forceinline__ void gemm_i8_wide_tile(const GemmArgs a0, const int v
 
     GemmArgs a = a0;
     TileSrc src;
-    select(a, vb, src);
+    select(a, vb_first, src);
     if constexpr (INT == 0) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
@@ -238,21 +254,26 @@ __device__ __forceinline__ void gemm_i8_wide_tile(const GemmArgs a0, const int v
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
-    __builtin_amdgcn_s_barrier();
-    if (ASYM && issuer && nkt > 1) issue(src, 1, 1);
-    if (ts) ts[1] = __builtin_readcyclecounter();
+    int vb = vb_first;
+    for (;;) {
+        // (persistent form, tiles after the first: stage 0 was requested before the previous tile's epilogue and has been
+        //  waited for at the bottom of this loop; this barrier also separates the previous epilogue's slab reads from the
+        //  stage-1 transfer that now overwrites them)
+        __builtin_amdgcn_s_barrier();
+        if (ASYM && issuer && nkt > 1) issue(src, 1, 1);
+        if (ts) ts[1] = __builtin_readcyclecounter();
 
-    int4v acc[TN][TM];
+        int4v acc[TN][TM];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
-    int4v xa[TM], xb[TM];
-    WRaw w[WR];
+            for (int i = 0; i < TM; ++i) acc[j][i] = int4v{0, 0, 0, 0};
+        int4v xa[TM], xb[TM];
+        WRaw w[WR];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) xa[i] = ldx(0, 0, i);
+        for (int i = 0; i < TM; ++i) xa[i] = ldx(0, 0, i);
 #pragma unroll
-    for (int k = 0; k < WPF; ++k) w[k % WR] = ldw(0, 0, k);
+        for (int k = 0; k < WPF; ++k) w[k % WR] = ldw(0, 0, k);
 
 #define VQ_WIDE_STEP(X, XN, H)                                                                             \
     {                                                                                                      \
@@ -285,41 +306,78 @@ __device__ __forceinline__ void gemm_i8_wide_tile(const GemmArgs a0, const int v
             __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                            \
         }                                                                                                  \
     }
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1, nxt = cur ^ 1;
-        const bool more = kt + 1 < nkt;
-        VQ_WIDE_STEP(xa, xb, 0)
-        VQ_WIDE_STEP(xb, xa, 1)
-    }
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1, nxt = cur ^ 1;
+            const bool more = kt + 1 < nkt;
+            VQ_WIDE_STEP(xa, xb, 0)
+            VQ_WIDE_STEP(xb, xa, 1)
+        }
 #undef VQ_WIDE_STEP
-    if (ts) ts[2] = __builtin_readcyclecounter();
-    const float* gate_row = EPI == VQ_EPI_GATE_RESID ? ring_tile_gate_row<BM>(a, src.m0) : nullptr;
-    // The dequantisation parameters are parked behind the epilogue slabs.  For the 256-row tile (and for W4 stages) that
-    // is past the end of the ring, so they can be written while slower waves still read fragments; for the 128-row tile
-    // with 128-byte weight rows the block lies INSIDE stage 1 - the stage the last k-tile occupies when their number is
-    // even (K = 256, 4608): parked before every wave had left the loop it overwrote weight rows under the last MFMAs
-    // (found by test_gemm_low_bit_weights).  There the global loads are issued first and the LDS writes wait for a
-    // workgroup barrier.
-    constexpr bool PAR_IN_RING = NW * WTM * (WTN * 2 + 16) < 2 * STAGE;
-    const auto colp = ring_load_col_params<BN, 64 * NW>(a, src.n0, tid, gate_row);
-    const RowParams rowp = ring_load_row_params<BM>(a, src.m0, tid);
-    if constexpr (PAR_IN_RING) __syncthreads();
-    ring_park_col_params<BM, BN, WAVES_M, WAVES_N, 16, true>(colp, smem, tid);
-    ring_park_row_params<BM, BN, WAVES_M, WAVES_N, 16, true>(rowp, smem, tid);
-    __syncthreads();
-    // (INT != 0: the launcher has checked what the interior epilogue needs for every tile - launch_gemm_wide_e)
-    ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI, 16, true, 0, INT != 0 && !STAMP>(a, smem, acc, src.m0, src.n0, ts, tid,
-                                                                                 gate_row != nullptr);
+        if (ts) ts[2] = __builtin_readcyclecounter();
+        // (persistent form: an opaque per-tile copy of the thread id, so that the epilogue's lane-derived addresses are
+        //  recomputed per tile instead of being hoisted out of the tile loop and kept - or spilled - through the main loop:
+        //  tools/lab/gemm_sp.hip found 48 such registers, and every scratch reload's vmcnt(0) waits for the DMA in flight)
+        int tid_e = tid;
+        if constexpr (PERSIST) asm volatile("" : "+v"(tid_e));
+        const float* gate_row = EPI == VQ_EPI_GATE_RESID ? ring_tile_gate_row<BM>(a, src.m0) : nullptr;
+        // The dequantisation parameters are parked behind the epilogue slabs.  For the 256-row tile (and for W4 stages, and
+        // in the persistent layout) that is outside both stages, so they can be written while slower waves still read
+        // fragments; for the 128-row tile with 128-byte weight rows the block lies INSIDE stage 1 - the stage the last
+        // k-tile occupies when their number is even (K = 256, 4608): parked before every wave had left the loop it
+        // overwrote weight rows under the last MFMAs (found by test_gemm_low_bit_weights).  There the global loads are
+        // issued first and the LDS writes wait for a workgroup barrier.
+        constexpr bool PAR_IN_RING = !PERSIST && NW * SLROWS * (WTN * 2 + 16) < 2 * STAGE;
+        const auto colp = ring_load_col_params<BN, 64 * NW>(a, src.n0, tid_e, gate_row);
+        const RowParams rowp = ring_load_row_params<BM>(a, src.m0, tid_e);
+        if constexpr (PAR_IN_RING) __syncthreads();
+        ring_park_col_params<BM, BN, WAVES_M, WAVES_N, 16, true, SROWS>(colp, smem, tid_e);
+        ring_park_row_params<BM, BN, WAVES_M, WAVES_N, 16, true, SROWS>(rowp, smem, tid_e);
+        __syncthreads();
+        // persistent form: every wave has left the main loop - stage 0 is free.  Request stage 0 of the next tile now; it
+        // lands during the dequantisation and the stores below.
+        const int vbn = vb + vb_step;
+        const bool has_next = PERSIST && vbn < ntiles;         // workgroup-uniform
+        GemmArgs an = a0;
+        TileSrc srcn = src;
+        if (has_next) {
+            select(an, vbn, srcn);
+            if (issuer) issue(srcn, 0, 0);
+        }
+        // (INT != 0: the launcher has checked what the interior epilogue needs for every tile - launch_gemm_wide_e)
+        ring_epilogue<BM, BN, WAVES_M, WAVES_N, EPI, 16, true, SROWS, INT != 0 && !STAMP>(a, smem, acc, src.m0, src.n0, ts, tid_e,
+                                                                                          gate_row != nullptr);
+        if (!has_next) break;
+        // the 17 stage-0 requests are OLDER than this wave's epilogue stores (and completed residual loads): vmcnt counts in
+        // order, so "at most as many outstanding as stores were issued since" means the transfer has landed, while the
+        // stores stay in flight under the next tile's first k-steps
+        constexpr int NST = (WTM * (WTN / 8)) / 64;            // 16-byte store instructions per wave and tile
+        static_assert(NST <= 63, "vmcnt field");
+        if (issuer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST) : "memory");
+        a = an;
+        src = srcn;
+        vb = vbn;
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4, bool STAMP = false, int INT = 0>
 __global__ __launch_bounds__(64 * WAVES_M* WAVES_N) void gemm_i8_wide_kernel(GemmArgs a) {
-    gemm_i8_wide_tile<BM, BN, WAVES_M, WAVES_N, EPI, W4, STAMP, INT>(a, blockIdx.x, threadIdx.x);
+    gemm_i8_wide_tiles<BM, BN, WAVES_M, WAVES_N, EPI, W4, STAMP, INT>(a, blockIdx.x, gridDim.x, threadIdx.x);
+}
+
+// number of CUs of the current device (the grid of the persistent form)
+static int vq_num_cus() {
+    static int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return ncu;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool W4, int INT = 0>
 static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
-    using Cfg = WideCfg<BM, BN, WAVES_M, WAVES_N, W4>;
+    using Cfg = WideCfg<BM, BN, WAVES_M, WAVES_N, W4, INT>;
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr size_t LDS = Cfg::LDS;
     const int MT = (a.M + BM - 1) / BM, NTl = (a.N + BN - 1) / BN;
@@ -336,7 +394,8 @@ static int launch_gemm_wide_e(const GemmArgs& a, hipStream_t st) {
         g_vq_last_hip_error = (int)e;
         return VQ_ELAUNCH;
     }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), LDS, st, a);
+    const int grid = Cfg::PERSIST ? (tiles < vq_num_cus() ? tiles : vq_num_cus()) : tiles;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS, st, a);
     return vq_check_launch();
 }
 

@@ -34,6 +34,8 @@ def lib():
         _lib.vq_lab_gemm_4w.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
         _lib.vq_lab_gemm_loader.restype = _i
         _lib.vq_lab_gemm_loader.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
+        _lib.vq_lab_gemm_persist6.restype = _i
+        _lib.vq_lab_gemm_persist6.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
         _lib.vq_lab_gemm_sp.restype = _i
         _lib.vq_lab_gemm_sp.argtypes = [_vp] * 10 + [_i, _vp, _vp] + [_i] * 8 + [_vp]
         _lib.vq_probe_mfma_i8.argtypes = [_vp, _vp, _vp, _vp]
@@ -83,6 +85,20 @@ def gemm_loader(a, w, bias=None, out=None, epilogue=0, resid=None, gate=None, ro
                                   epilogue, variant, torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise RuntimeError("vq_lab_gemm_loader mode %d variant %d: error %d" % (mode, variant, rc))
+    return out
+
+
+def gemm_persist6(a, w, bias=None, out=None, epilogue=0, resid=None, gate=None, rows_per_gate=0, mode=2):
+    """tools/lab/gemm_persist6.hip: mode 2 = the interior GEMM as persistent workgroups with next-tile prefetch (round 6),
+    mode 1 = the same header's interior form"""
+    M, N = a.rows, w.N
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=a.xq.device)
+    rc = lib().vq_lab_gemm_persist6(_p(a.xq), _p(a.sx), _p(a.zx), _p(a.R), _p(w.wq), _p(w.sw), _p(w.zw), _p(w.cs), _p(bias),
+                                    _p(out), out.stride(0), _p(resid), _p(gate), rows_per_gate, M, N, a.K, a.Kp, mode,
+                                    epilogue, w.n_bits, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError("vq_lab_gemm_persist6 mode %d: error %d" % (mode, rc))
     return out
 
 

@@ -74,7 +74,11 @@ def load(path: str = LIB_PATH):
     return lib
 
 
+CALLS = [0]      # C-ABI calls checked so far (graph.StepGraph differences it around a capture: the census of bench.py)
+
+
 def check(code: int, what: str = ""):
+    CALLS[0] += 1
     if code != VQ_OK:
         lib = load()
         msg = lib.vq_strerror(code).decode()

@@ -513,6 +513,26 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
         const bool has_next = npos_next < npos;    // workgroup-uniform; its rows are already in flight
         int tx = tid;
         asm volatile("" : "+v"(tx));
+#if defined(VQ_TEMPORAL_ABL) && VQ_TEMPORAL_ABL == 2   // measurement build (results wrong): memory traffic only
+        if (has_next) {
+            __builtin_amdgcn_s_barrier();
+            store_qkv(tx);
+            if (npos_next + (int)gridDim.x < npos) load_qkv(npos_next + (int)gridDim.x, tx);
+        }
+        __builtin_amdgcn_s_barrier();
+        {
+            const int kch = a.Kp / 16, cch = C / 16;
+            for (int c = tid; c < 16 * kch; c += nthr) {
+                const int t = c / kch, ch = c - t * kch;
+                if (t < a.T) {
+                    const long grow = ((long)b * a.T + t) * a.S + s;
+                    const int4v val = ch < cch ? *reinterpret_cast<const int4v*>(codes + t * CROW + ch * 16) : int4v{0, 0, 0, 0};
+                    *reinterpret_cast<int4v*>(a.xq + grow * a.Kp + ch * 16) = val;
+                }
+            }
+        }
+        continue;
+#endif
 
         // ---- S^T[key 4*g4 + r][query tq] = K Q^T, 16 x 16 per head: lane holds 8 dims of key row tq and of query row tq
         float4v sc = {0.f, 0.f, 0.f, 0.f};
@@ -607,7 +627,9 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
                 kfc[ks] = kfn[ks];
                 qfc[ks] = qfn[ks];
             }
+#if !(defined(VQ_TEMPORAL_ABL) && VQ_TEMPORAL_ABL == 1)   // (measurement build 1, results wrong: compute and stores only)
             if (npos_next + (int)gridDim.x < npos) load_qkv(npos_next + (int)gridDim.x, tx);   // ... and the position after it is requested
+#endif
         }
         vmin = INFINITY;
         vmax = -INFINITY;
@@ -1189,10 +1211,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_fwd32d_kernel(A
                 // tile's exponentials - a garbage running max, rows of zeros / NaN).  So the first read of the fresh
                 // accumulator is a compiler-visible VALU instruction (x + 0.0f is not foldable); the asm chain depends on it.
                 const float s0 = s[0] + 0.0f;
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s0), "v"(s[1]), "v"(s[2]));
-#pragma unroll
-                for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[r]), "v"(s[r + 1]));
-                asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[15]));
+                // ONE statement for the whole chain: between two dependent asm statements the compiler pads a wait state
+                // (an asm producer may write with dst_sel: DstSelForwardingHazard) - 8 s_nop per 32-key half otherwise
+                asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\t"
+                    "v_max3_f32 %0, %0, %8, %9\n\tv_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\t"
+                    "v_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
+                    : "=&v"(mx)
+                    : "v"(s0), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]),
+                      "v"(s[10]), "v"(s[11]), "v"(s[12]), "v"(s[13]), "v"(s[14]), "v"(s[15]));
                 const unsigned mb = __builtin_bit_cast(unsigned, mx);
                 const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
                 asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(sw[0]), "v"(sw[1]));
@@ -1210,14 +1236,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_fwd32d_kernel(A
             const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * a.c;
             half8 pf[2];
             {
-                typedef float float2v __attribute__((ext_vector_type(2)));
-                const float2v cc2 = {a.c, a.c}, mm2 = {-mc, -mc};
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    float2v t = {s[r], s[r + 1]};
-                    t = __builtin_elementwise_fma(t, cc2, mm2);      // v_pk_fma_f32
-                    pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(t[0]);
-                    pf[r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t[1]);
+                    // two plain v_fma_f32, NOT one v_pk_fma_f32: beside the partner waves' MFMAs the packed form costs more than
+                    // the issue slot it saves (and a forwarding wait state in front of v_exp) - round 6, one box, alternating x 3:
+                    // 115.4 -> 111.0 us at 16 x 1024 x 1024, 187.3 -> 177.6 us at 2 x 4096 x 4096 (profiles/r06_experiments.md 1)
+                    const float t0 = __builtin_fmaf(s[r], a.c, -mc), t1 = __builtin_fmaf(s[r + 1], a.c, -mc);
+                    pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(t0);
+                    pf[r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t1);
                 }
             }
             if constexpr ((ABLD & 16) != 0) {
@@ -1506,13 +1532,11 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
             const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * a.c;
             half8 pf[2];
             {
-                const float2v cc2 = {a.c, a.c}, mm2 = {-mc, -mc};
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    float2v t = {s[r], s[r + 1]};
-                    t = __builtin_elementwise_fma(t, cc2, mm2);      // v_pk_fma_f32
-                    pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(t[0]);
-                    pf[r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t[1]);
+                for (int r = 0; r < 16; r += 2) {                    // plain v_fma_f32 as in attn_fwd32d_kernel (here memory-bound: 42.2 vs 42.4 us, round 6)
+                    const float t0 = __builtin_fmaf(s[r], a.c, -mc), t1 = __builtin_fmaf(s[r + 1], a.c, -mc);
+                    pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(t0);
+                    pf[r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t1);
                 }
             }
 #pragma unroll

@@ -27,7 +27,6 @@
 //
 // Roofline: MFMA-bound (int8 dense peak 5.03 POPS); algorithmic bytes M*K + N*K(/2) + 2*M*N (+2*M*N
 // when a residual is read).
-#include <stdlib.h>
 #include "gemm_wide.h"
 
 // Tile height by shape.  A 128-row tile costs ~0.62 of a 256-row one (tools/gemm_half_tiles.py: 17.2 vs 23.1 us at
@@ -39,31 +38,10 @@ static bool vq_half_tiles(int M, int N, int sets) {
     const long r128 = (((M + 127) / 128) * nt + 255) / 256, r256 = (((M + 255) / 256) * nt + 255) / 256;
     return r128 * 5 < r256 * 8;
 }
-// Twelve waves (4 x 3, wave tile 64 x 96, three waves per SIMD; gemm_wide.h instantiated as <256, 288, 4, 3>) for launches
-// made of interior tiles only (its epilogue runs through half slabs, which exist for interior tiles): `variant` 18.
-// Bit-identical to the 8-wave form (tested).  Back to back it ties on three-round K = 1152 launches, loses 3-5 % on
-// single-round ones and wins on the long ones (fc1, N = 4608, four rounds: 107 -> 95 us; fc2, K = 4608: 84 -> 80 us); INSIDE
-// the two-stream step it loses wherever it is used: 25.12 / 25.19 steps/s without it, 25.01 / 25.05 for fc1 + fc2 only,
-// 24.80 for every multi-round launch, 24.82 everywhere (profiles/r04_gemm_12wave.md).  So it is OFF by default;
-// VQ_GEMM_12W = 1 (N >= 4608 or K >= 4608), 2 (every multi-round launch) or 3 (every interior launch) turn it on for A/B runs.
-static bool vq_use_12w(const GemmArgs& a, int sets) {
-    static const int mode = getenv("VQ_GEMM_12W") ? atoi(getenv("VQ_GEMM_12W")) : 0;
-    if (mode <= 0 || a.M % 256 != 0 || a.N % 288 != 0 || (a.N & 7) != 0 || (a.ldo & 7) != 0) return false;
-    if (a.epilogue == VQ_EPI_GATE_RESID && (a.rows_per_gate % 256) != 0) return false;   // the gate must fold into the staged scales
-    const long tiles = (long)(a.M / 256) * (a.N / 288) * sets;
-    if (mode >= 3) return true;
-    if (mode == 2) return tiles > 256 || a.Kp >= 4608;
-    return a.N >= 4608 || a.Kp >= 4608;
-}
 // Launches made of interior tiles only (M % tile height == 0, N % 288 == 0) take the scalar-addressed form of the same
 // kernel with asymmetric DMA issue (gemm_wide.h, INT 1: waves 0-3 issue every stage piece): `variant` 19, and the library's
 // own choice for such shapes - every Linear of the benchmarked STDiT / PixArt-Sigma configurations.  Bit-identical to the
-// general form (tested).  VQ_GEMM_INT = 0 keeps the general form everywhere, 2 selects the measurement arm (scalar
-// addressing, every wave issuing), 3 the half-slab epilogue (136 KiB of LDS per workgroup) - A/B runs on one box.
-static int vq_int_mode() {
-    static const int mode = getenv("VQ_GEMM_INT") ? atoi(getenv("VQ_GEMM_INT")) : 1;
-    return mode;
-}
+// general form (tested).
 template <bool W4>
 static int launch_gemm_auto(const GemmArgs& a, hipStream_t st, int variant) {
     const int sets = a.nbatch > 1 ? a.nbatch : a.ngroups > 1 ? a.ngroups : 1;
@@ -71,24 +49,10 @@ static int launch_gemm_auto(const GemmArgs& a, hipStream_t st, int variant) {
     const int bm = half ? 128 : 256;
     const bool interior = a.M % bm == 0 && a.N % 288 == 0 && (a.ldo & 7) == 0 &&
                           (a.epilogue != VQ_EPI_GATE_RESID || a.rows_per_gate % bm == 0);   // what the interior form's epilogue needs
-    const int im = variant == 19 ? 1 : (variant == VQ_GEMM_DEFAULT && interior) ? vq_int_mode() : 0;
-    if (variant == 19 && !interior) return VQ_ESHAPE;
-    // the twelve-wave form (VQ_GEMM_12W, off by default) in its interior form as well: scalar addressing, six issuing waves
-    if (im != 0 && !half && variant == VQ_GEMM_DEFAULT && vq_use_12w(a, sets)) return launch_gemm_wide<256, 288, 4, 3, true, W4, 1>(a, st);
-    if (im == 3) {   // half epilogue slabs: exist for the interior EPILOGUE only (8-byte aligned rows, gate folded into the scales)
-        if (!half) return launch_gemm_wide<256, 288, 4, 2, true, W4, 3>(a, st);
-        return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 1>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 1>(a, st);
-    }
-    if (im == 1) return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 1>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 1>(a, st);
-    if (im == 2) return half ? launch_gemm_wide<128, 288, 4, 2, true, W4, 2>(a, st) : launch_gemm_wide<256, 288, 4, 2, true, W4, 2>(a, st);
-    if (half) return launch_gemm_wide<128, 288, 4, 2, true, W4>(a, st);
-    if (variant == 18 || (variant == VQ_GEMM_DEFAULT && vq_use_12w(a, sets))) {
-        if (a.M % 256 != 0 || a.N % 288 != 0 || (a.N & 7) != 0 || (a.ldo & 7) != 0 ||
-            (a.epilogue == VQ_EPI_GATE_RESID && (a.rows_per_gate % 256) != 0))
-            return variant == 18 ? VQ_ESHAPE : launch_gemm_wide<256, 288, 4, 2, true, W4>(a, st);
-        return launch_gemm_wide<256, 288, 4, 3, true, W4>(a, st);
-    }
-    return launch_gemm_wide<256, 288, 4, 2, true, W4>(a, st);
+    if (variant == 19 && (!interior || half)) return VQ_ESHAPE;
+    if (variant == 19 || (variant == VQ_GEMM_DEFAULT && interior))
+        return half ? launch_gemm_wide<128, 288, 4, 2, W4, 1>(a, st) : launch_gemm_wide<256, 288, 4, 2, W4, 1>(a, st);
+    return half ? launch_gemm_wide<128, 288, 4, 2, W4>(a, st) : launch_gemm_wide<256, 288, 4, 2, W4>(a, st);
 }
 extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, const int32_t* R, const void* wq,
                           const float* sw, const int32_t* zw, const int32_t* cs, const float* bias, void* out,
@@ -112,8 +76,8 @@ extern "C" int vq_gemm_i8(const int8_t* xq, const float* sx, const int32_t* zx, 
         case VQ_GEMM_DEFAULT:  // tile height by shape (vq_half_tiles)
         case 11:               // 256 x 288 tile: full-line double buffer, 128 bytes of k per row and stage, staggered DMA issue
         case 16:               // 128 x 288 tile of the same kernel
-        case 18:               // 256 x 288 tile, twelve waves of 64 x 96 (interior tiles only: VQ_ESHAPE otherwise)
-        case 19:               // 256 x 288 tile, interior form: scalar-addressed pieces, waves 0-3 issue (VQ_ESHAPE unless M % 256 == 0, N % 288 == 0)
+        case 19:               // 256 x 288 tile, interior form: scalar-addressed pieces, waves 0-3 issue (VQ_ESHAPE unless M % 256 == 0,
+                               // N % 288 == 0, ldo % 8 == 0 and - gate epilogue - rows_per_gate % 256 == 0)
             if (w_bits <= 4) return launch_gemm_auto<true>(a, st, variant);
             return launch_gemm_auto<false>(a, st, variant);
         default:

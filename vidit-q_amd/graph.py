@@ -11,6 +11,7 @@ per-layer bit widths and FP layer set differ between keys, iddpm.TimestepMP).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Hashable, Optional, Tuple
 
 import torch
@@ -45,10 +46,25 @@ class StepGraph:
                 self._forward(timestep_id)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        dump = os.environ.get("VQ_GRAPH_DUMP")          # measurement: a .dot file of the captured graph (node census, bench.py)
+        if dump:
+            self.graph.enable_debug_mode()
+        from . import _lib
+        calls0 = _lib.CALLS[0]
         # thread_local: with a process group alive (N > 1) the RCCL watchdog thread polls events while we capture; in
         # the default 'global' mode such a call from ANOTHER thread would invalidate the capture
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.cond, self.uncond = self._forward(timestep_id)
+        # C-ABI calls recorded into the graph (= its HIP-kernel nodes from this library: one launch per entry point, the
+        # fast quantizer entry points included; the ~60 torch elementwise kernels of the FP edges come on top)
+        self.c_abi_calls = _lib.CALLS[0] - calls0
+        self.dot_path = None
+        if dump:
+            try:
+                self.dot_path = "%s.%d.dot" % (dump, id(self))
+                self.graph.debug_dump(self.dot_path)
+            except Exception:                           # the census is optional; the capture itself stands
+                self.dot_path = None
 
     def _forward(self, t_id, serial=False):
         q = self.qnn

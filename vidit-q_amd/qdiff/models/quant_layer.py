@@ -287,9 +287,11 @@ class QuantLayer(nn.Module):
         if not isinstance(self.act_quantizer, DynamicActQuantizer):
             return False
         # B = 2 with a smoothing vector: the LDS-staged pair kernel when the vector has a usable reciprocal and the row is
-        # long, else the register pair kernel (exact division when ops.smooth_rcp(s) is None) - never a refusal after the
-        # producing GEMM was launched with the plain epilogue
-        return B in (1, 2)
+        # long, else the register pair kernel (exact division when ops.smooth_rcp(s) is None).  What vq_gelu_rowquant itself
+        # refuses is mirrored HERE (rows of whole 16-byte chunks, at most 4608 padded channels: rowquant_fast.hip
+        # vq_gelu_rowquant_fast / _pair_fast) - the answer picks the producing GEMM's epilogue, so a refusal after that GEMM
+        # was launched with the plain epilogue would be a hard error (round-5 advisor: K = 6144)
+        return B in (1, 2) and K % 8 == 0 and ops.pad128(K) <= 4608
 
     def quantize_gelu_input(self, h3: torch.Tensor, s: Optional[torch.Tensor]) -> Optional[ops.QAct]:
         """act(GELU tanh) + this layer's activation quantizer in one pass over the PRE-activation ``h3`` [B, n, K], B = 1

@@ -88,7 +88,14 @@ def fp_edge_linear(layer, x, act_in=0, act_out=0):
     # module path (round-4 advisor finding: the graph was silently cut and forward hooks skipped)
     if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
         return None
-    if getattr(layer, "_forward_hooks", None) or getattr(layer, "_forward_pre_hooks", None):
+    if getattr(layer, "_forward_hooks", None) or getattr(layer, "_forward_pre_hooks", None) or getattr(
+            layer, "_backward_hooks", None) or getattr(layer, "_backward_pre_hooks", None):
+        return None
+    # hooks registered for EVERY module (torch.nn.modules.module.register_module_forward_hook and friends: calibration /
+    # observer tooling) see the module path only - round-5 advisor
+    gm = torch.nn.modules.module
+    if getattr(gm, "_global_forward_hooks", None) or getattr(gm, "_global_forward_pre_hooks", None) or getattr(
+            gm, "_global_backward_hooks", None) or getattr(gm, "_global_backward_pre_hooks", None):
         return None
     # the edge kernel is built for SKINNY problems (one 16 x 16 output tile per workgroup, no operand reuse): few rows, few
     # columns or a short contraction.  A full-size FP Linear (16384 x 4608 x 1152: the block MLP of an FP calibration
