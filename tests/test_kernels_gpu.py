@@ -618,6 +618,58 @@ def test_attn_fwd_long_ragged_rectangular(ops, dev, n_seq, Lq, Lk, H, D):
     assert (o.cpu().float() - ref).abs().max() < 4e-3
 
 
+@pytest.mark.parametrize("n_seq,Lq,Lk,H,D", [(1, 2048, 2048, 2, 72), (2, 2100, 2077, 1, 72), (1, 2560, 4100, 2, 64), (1, 2049, 2048, 3, 32),
+                                             (1, 4096, 2500, 2, 16)])
+def test_attn_fwd_sixty_four_queries_per_wave_kernel(ops, dev, n_seq, Lq, Lk, H, D):
+    """Long images (Lq, Lk >= 2048: PixArt-Sigma's 4096 tokens) take attn_fwd64d_kernel (round 6: 64 queries per wave, two
+    waves per SIMD, every K / V fragment read feeds two MFMAs): ragged query tiles (the last workgroup has whole waves and
+    half waves without rows), ragged key tiles, every head dim, against the fp32 softmax reference; and the V == 1
+    invariance on the same shapes.  (Per query row its arithmetic is attn_fwd32d_kernel's: bit-identical outputs at
+    16 x 1024, 2 x 4096 and 3 x 1000 tokens, tools/attn_ab.py --dump / --cmp.)"""
+    Cc = H * D
+    q = h16(n_seq * Lq, Cc, scale=1.0, seed=Lq + D).to(dev)
+    kv = h16(n_seq * Lk, 2 * Cc, scale=1.0, seed=Lk + D).to(dev)
+    o = torch.full((n_seq * Lq, Cc), float("nan"), dtype=torch.float16, device=dev)
+    ops.attn_fwd(q, kv, kv[:, Cc:], o, n_seq, Lq, Lk, H, D, Lq * Cc, Cc, Lk * 2 * Cc, 2 * Cc, Lq * Cc, Cc)
+    ref = _attn_ref(q.cpu().reshape(n_seq, Lq, H, D), kv[:, :Cc].cpu().reshape(n_seq, Lk, H, D),
+                    kv[:, Cc:].cpu().reshape(n_seq, Lk, H, D), D ** -0.5).reshape(n_seq * Lq, Cc)
+    assert torch.isfinite(o).all()
+    assert rel_l2(o.cpu().float(), ref) < 1e-3
+    assert (o.cpu().float() - ref).abs().max() < 4e-3
+    kv[:, Cc:] = 1.0
+    o.zero_()
+    ops.attn_fwd(q, kv, kv[:, Cc:], o, n_seq, Lq, Lk, H, D, Lq * Cc, Cc, Lk * 2 * Cc, 2 * Cc, Lq * Cc, Cc)
+    assert float((o.float() - 1.0).abs().max()) <= 2.0 ** -10
+
+
+def test_attn_cross_row_maximum_covers_every_key_of_a_tile(ops, dev):
+    """Round-6 finding: attn_cross32_kernel took its running maximum over HALF of the keys of every 32-key tile (hipcc read
+    element 0 of the lane-swap builtin's result for both operands of a bit cast).  The softmax stayed exact, but a key of the
+    unseen half far above the others made P = exp2(s - m) overflow fp16: inf / NaN outputs.  Here ONE key per row block,
+    placed in each residue class of the 32-key tile in turn, scores 40 above the rest in the exp2 domain (2^40 >> 65504)."""
+    H, D, Nq, Lk = 2, 72, 512, 96
+    Cc = H * D
+    g = torch.Generator().manual_seed(11)
+    q = (torch.randn(Nq, Cc, generator=g) * 0.3).half()
+    scale = D ** -0.5
+    for hot in range(0, 32, 3):
+        kv = (torch.randn(Lk, 2 * Cc, generator=g) * 0.3).half()
+        # key `hot + 32` of every head points along the mean query direction, long enough for a score ~ 30 / log2(e) above
+        for h in range(H):
+            dirn = q[:, h * D:(h + 1) * D].float().mean(0)
+            dirn = dirn / dirn.norm()
+            kv[hot + 32, h * D:(h + 1) * D] = (dirn * 60.0).half()
+            q[:, h * D:(h + 1) * D] = (q[:, h * D:(h + 1) * D].float() + dirn * 6.0).half()
+        off = torch.tensor([0, Lk], dtype=torch.int32, device=dev)
+        o = torch.zeros((Nq, Cc), dtype=torch.float16, device=dev)
+        kvd = kv.to(dev)       # (key bound known: the K / V-in-LDS kernel, as the model calls it)
+        ops.attn_fwd(q.to(dev), kvd, kvd[:, Cc:], o, 1, Nq, Lk, H, D, Nq * Cc, Cc, 0, 2 * Cc, Nq * Cc, Cc, kv_off=off)
+        ref = _attn_ref(q.reshape(1, Nq, H, D), kv[:, :Cc].reshape(1, Lk, H, D), kv[:, Cc:].reshape(1, Lk, H, D), scale).reshape(Nq, Cc)
+        assert torch.isfinite(o).all(), hot
+        assert rel_l2(o.cpu().float(), ref) < 2e-3, hot
+        q = (torch.randn(Nq, Cc, generator=g) * 0.3).half()
+
+
 @pytest.mark.parametrize("D", [16, 32, 64, 72])
 @pytest.mark.parametrize("n_seq,Lq,Lk,H", [(1, 256, 256, 1), (2, 512, 320, 4), (4, 1024, 1024, 16)])
 def test_attn_fwd_constant_values_come_back_exactly(ops, dev, D, n_seq, Lq, Lk, H):

@@ -39,6 +39,25 @@ def timeit(fn, n=8, reps=10):
 
 tag = os.path.basename(os.path.dirname(_lib.LIB_PATH))
 out = []
+# --dump=<file> / --cmp=<file>: the spatial / image outputs of a fixed input, saved by one library and compared bit for bit by another
+DUMP = next((w[7:] for w in WHICH if w.startswith("--dump=")), None)
+CMP = next((w[6:] for w in WHICH if w.startswith("--cmp=")), None)
+if DUMP or CMP:
+    res = {}
+    for name, n_seq, L in (("spatial", 16, 1024), ("image", 2, 4096), ("ragged", 3, 1000)):
+        M = n_seq * L
+        q = (torch.randn(M, 3 * 1152, generator=torch.Generator().manual_seed(7)) * 1.3).half().to(dev)
+        o = torch.zeros((M, 1152), dtype=torch.float16, device=dev)
+        ops.attn_fwd(q, q[:, 1152:], q[:, 2304:], o, n_seq, L, L, H, D, L * 3456, 3456, L * 3456, 3456, L * 1152, 1152)
+        res[name] = o.cpu()
+    if DUMP:
+        torch.save(res, DUMP)
+        print("%-16s dumped %s" % (tag, DUMP))
+    else:
+        ref = torch.load(CMP)
+        print("%-16s vs %s: %s" % (tag, CMP, ", ".join("%s %s (max |d| %.3g)" % (
+            k, "bit-identical" if torch.equal(res[k], ref[k]) else "DIFFERS", float((res[k].float() - ref[k].float()).abs().max())) for k in res)))
+    sys.exit(0)
 for name, n_seq, L in (("spatial", 16, 1024), ("image", 2, 4096)):
     if name not in WHICH:
         continue

@@ -513,26 +513,6 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
         const bool has_next = npos_next < npos;    // workgroup-uniform; its rows are already in flight
         int tx = tid;
         asm volatile("" : "+v"(tx));
-#if defined(VQ_TEMPORAL_ABL) && VQ_TEMPORAL_ABL == 2   // measurement build (results wrong): memory traffic only
-        if (has_next) {
-            __builtin_amdgcn_s_barrier();
-            store_qkv(tx);
-            if (npos_next + (int)gridDim.x < npos) load_qkv(npos_next + (int)gridDim.x, tx);
-        }
-        __builtin_amdgcn_s_barrier();
-        {
-            const int kch = a.Kp / 16, cch = C / 16;
-            for (int c = tid; c < 16 * kch; c += nthr) {
-                const int t = c / kch, ch = c - t * kch;
-                if (t < a.T) {
-                    const long grow = ((long)b * a.T + t) * a.S + s;
-                    const int4v val = ch < cch ? *reinterpret_cast<const int4v*>(codes + t * CROW + ch * 16) : int4v{0, 0, 0, 0};
-                    *reinterpret_cast<int4v*>(a.xq + grow * a.Kp + ch * 16) = val;
-                }
-            }
-        }
-        continue;
-#endif
 
         // ---- S^T[key 4*g4 + r][query tq] = K Q^T, 16 x 16 per head: lane holds 8 dims of key row tq and of query row tq
         float4v sc = {0.f, 0.f, 0.f, 0.f};
@@ -627,9 +607,7 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
                 kfc[ks] = kfn[ks];
                 qfc[ks] = qfn[ks];
             }
-#if !(defined(VQ_TEMPORAL_ABL) && VQ_TEMPORAL_ABL == 1)   // (measurement build 1, results wrong: compute and stores only)
             if (npos_next + (int)gridDim.x < npos) load_qkv(npos_next + (int)gridDim.x, tx);   // ... and the position after it is requested
-#endif
         }
         vmin = INFINITY;
         vmax = -INFINITY;
@@ -679,6 +657,285 @@ __global__ __launch_bounds__(1024) void attn_temporal_quant_kernel(TempQArgs a) 
             int rs = 0;
             for (int w = 0; w < H; ++w) rs += ex_sum[w * 16 + tq];
             const long grow = ((long)b * a.T + tq) * a.S + s;
+            a.sx[grow] = delta;
+            a.zx[grow] = izx;
+            a.R[grow] = rs - 128 * C - C * izx;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// attn_temporal_quant2_kernel (round 6): the kernel above for H = 16 heads with its per-position INSTRUCTION count cut.
+// Ablations of the kernel above (profiles/r06_experiments.md 6: 38.8 us; loads only 11.7 us; compute + stores only 27.9 us)
+// showed it bound by its own instruction stream - ~1300 static instructions per position and wave, 16 waves in lockstep
+// between two barriers - not by the 132 MB it moves.  Here:
+//   * every global access is SGPR base (per position, scalar arithmetic) + a 32-bit per-lane offset computed ONCE (the kernel
+//     above recomputed five 64-bit addresses per position with v_mad_u64_u32 / v_mul_lo_u32 chains to save registers);
+//   * the K / Q operand registers are requested again right behind the QK^T MFMAs that consume them - one set, no copy of
+//     a "next" set into a "current" one (24 registers and 24 moves per position less: the spill of the kernel above is gone);
+//   * the cross-row reductions over the four 16-lane rows of a wave are v_permlane16_swap / v_permlane32_swap + one VALU
+//     instruction each instead of ds_bpermute round trips (ten dependent LDS latencies per position);
+//   * 1 / sum(p) is v_rcp_f32 (1 ulp; the fp16 rounding that follows is 2^13 times coarser) instead of an IEEE division;
+//   * the chunk -> (row, column) decomposition of the code stores is per-lane state, not a division per chunk.
+// Codes / grids / row sums remain exact functions of the kernel's own fp16 output (bit-identical to vq_rowquant of it: same
+// vq_row_grid / rq_round_group arithmetic, tested).
+// ---------------------------------------------------------------------------
+// (the swap builtins return a 2-vector: its elements are copied into scalars before any __builtin_bit_cast - written on the
+//  vector elements directly, hipcc of ROCm 7.2 reads element 0 for both)
+__device__ __forceinline__ float tq_xor16(float x, bool is_max) {     // combine rows (0,1) and (2,3) of the wave
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    float m;      // (asm: fmaxf / fminf would canonicalise both operands first - two more instructions per reduction step)
+    if (is_max) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
+    else asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
+    return m;
+}
+__device__ __forceinline__ float tq_xor32(float x, bool is_max) {     // combine the two halves of the wave
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    float m;      // (asm: fmaxf / fminf would canonicalise both operands first - two more instructions per reduction step)
+    if (is_max) asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
+    else asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
+    return m;
+}
+__device__ __forceinline__ float tq_sum4rows(float x) {
+    unsigned b = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    unsigned r0 = r[0], r1 = r[1];
+    x = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+    b = __builtin_bit_cast(unsigned, x);
+    r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    r0 = r[0], r1 = r[1];
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ int tq_isum4rows(int x) {
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    x = (int)r[0] + (int)r[1];
+    r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return (int)r[0] + (int)r[1];
+}
+
+template <int D>
+__global__ __launch_bounds__(1024) void attn_temporal_quant2_kernel(TempQArgs a) {
+    constexpr int H = 16, C = H * D, NTHR = 64 * H;
+    constexpr int KS = (D + 15) / 16, KS2 = (D + 31) / 32;
+    constexpr int RS = C * 2 + 16, TILE = 16 * RS, RCH = C / 8, CROW = C + 16;
+    constexpr int NIT = (16 * RCH + NTHR - 1) / NTHR;      // V chunks per thread (3 at D = 72)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = head
+    const int tq = lane & 15, g4 = lane >> 4;
+    uint8_t* codes = smem + TILE;
+    float* ex_min = reinterpret_cast<float*>(codes + 16 * CROW);
+    float* ex_max = ex_min + 256;
+    int* ex_sum = reinterpret_cast<int*>(ex_max + 256);
+    const int npos = a.S * a.B, G = (int)gridDim.x;
+    const unsigned tstride = (unsigned)a.S * (unsigned)a.ld_in * 2u;          // bytes between the rows t, t + 1 of a position
+
+    // ---- per-lane state, computed once -----------------------------------------------------------------------------
+    unsigned vgo[NIT], vlo[NIT];                           // V chunk: global byte offset from the position's base, LDS offset
+    bool vok[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int c = tid + i * NTHR;
+        const int t = c / RCH, ch = c - t * RCH;
+        vok[i] = c < 16 * RCH && t < a.T;
+        vgo[i] = (unsigned)t * tstride + (unsigned)ch * 16u;
+        vlo[i] = (unsigned)(t * RS + ch * 16);
+    }
+    const bool kq_row = tq < a.T;
+    const unsigned kqo = (unsigned)(kq_row ? tq : 0) * tstride + (unsigned)(wave * D + 8 * g4) * 2u;   // + 64 bytes per k-step
+    const int kch = a.Kp / 16, cch = C / 16;
+    constexpr int NCI = 2;                                 // code chunks per thread: 16 rows x Kp / 16 <= 2048 (Kp <= 2048)
+    unsigned cgo[NCI], clo[NCI];
+    bool cok[NCI], cpad[NCI];
+#pragma unroll
+    for (int j = 0; j < NCI; ++j) {
+        const int c = tid + j * NTHR;
+        const int t = c / kch, ch = c - t * kch;
+        cok[j] = c < 16 * kch && t < a.T;
+        cpad[j] = ch >= cch;
+        cgo[j] = (unsigned)t * (unsigned)a.S * (unsigned)a.Kp + (unsigned)ch * 16u;
+        clo[j] = (unsigned)(t * CROW + ch * 16);
+    }
+    const uint8_t* vs = smem + wave * D * 2;
+    const unsigned vtro = (unsigned)((4 * g4 + (tq >> 2)) * RS + 4 * (tq & 3) * 2);   // transpose-read lane offset (+ 32 bytes per dim tile)
+
+    int4v vals[NIT];
+    half8 kf[KS2], qf[KS2];
+    auto base_of = [&](int pos) -> size_t {                // first row (t = 0) of the position, in ELEMENTS of ld_in rows
+        const int s = pos % a.S, b = pos / a.S;
+        return ((size_t)b * a.T * a.S + s);
+    };
+    auto load_v = [&](int pos) {
+        const uint8_t* vb = reinterpret_cast<const uint8_t*>(a.v) + base_of(pos) * (size_t)a.ld_in * 2;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            if (vok[i]) vals[i] = *reinterpret_cast<const int4v*>(vb + vgo[i]);   // (lanes without a chunk keep their zeros)
+    };
+    auto load_kq = [&](int pos) {
+        const size_t bo = base_of(pos) * (size_t)a.ld_in * 2;
+        const uint8_t* kb = reinterpret_cast<const uint8_t*>(a.k) + bo;
+        const uint8_t* qb = reinterpret_cast<const uint8_t*>(a.q) + bo;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+            if (ks * 32 + 8 * g4 < D && kq_row) {          // (dims >= D / rows >= T: the registers keep the zeros set below)
+                kf[ks] = *reinterpret_cast<const half8*>(kb + kqo + ks * 64);
+                qf[ks] = *reinterpret_cast<const half8*>(qb + kqo + ks * 64);
+            }
+    };
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) vals[i] = int4v{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            kf[ks][e] = (half_t)0.f;
+            qf[ks][e] = (half_t)0.f;
+        }
+    auto store_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            if (tid + i * NTHR < 16 * RCH) *reinterpret_cast<int4v*>(smem + vlo[i]) = vals[i];
+    };
+
+    int pos = blockIdx.x;
+    if (pos >= npos) return;
+    load_v(pos);
+    load_kq(pos);
+    store_v();
+    __syncthreads();
+    if (pos + G < npos) load_v(pos + G);
+    for (; pos < npos; pos += G) {
+        const int pos_n = pos + G;
+        const bool has_next = pos_n < npos;                // workgroup-uniform
+        const size_t row0 = base_of(pos);
+
+        // ---- S^T = K Q^T (16 x 16 per head), then the operand registers are requested again for the next position
+        float4v sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[ks], qf[ks], sc, 0, 0, 0);
+        if (has_next) load_kq(pos_n);
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (4 * g4 + r >= a.T) sc[r] = -INFINITY;
+            mloc = fmaxf(mloc, sc[r]);
+        }
+        mloc = tq_xor32(tq_xor16(mloc, true), true);
+        const float m_use = (mloc == -INFINITY) ? 0.f : mloc;
+        float psum = 0.f;
+        half4 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f((sc[r] - m_use) * a.c);
+            psum += p;
+            pf[r] = (half_t)p;
+        }
+        psum = tq_sum4rows(psum);
+        const float inv_p = psum > 0.f ? __builtin_amdgcn_rcpf(psum) : 0.f;
+
+        // ---- O^T = V^T P^T, rounded to fp16 as the stored tensor is
+        float ov[KS][4];
+        float vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+        for (int dt = 0; dt < KS; ++dt) {
+            const h4t_t vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (__attribute__((address_space(3))) h4t_t*)(vs + vtro + dt * 32));
+            const half4 vf = {(half_t)vt[0], (half_t)vt[1], (half_t)vt[2], (half_t)vt[3]};
+            const float4v o4 = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[dt][r] = (float)(half_t)(o4[r] * inv_p);
+        }
+        if (a.o && tq < a.T) {                             // optional fp16 copy (tests, callers that need both)
+            half_t* orow = a.o + (row0 + (size_t)tq * a.S) * C + wave * D;
+#pragma unroll
+            for (int dt = 0; dt < KS; ++dt) {
+                const int d0 = dt * 16 + 4 * g4;
+                if (d0 < D) {
+                    half4 o4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o4[r] = (half_t)ov[dt][r];
+                    *reinterpret_cast<half4*>(orow + d0) = o4;
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < KS; ++dt) {
+            const int d0 = dt * 16 + 4 * g4;
+            if (d0 < D) {
+                if (a.s) {                                 // kernel-uniform: x / s of the consuming Linear's smoothing vector
+                    const float4v s4 = *reinterpret_cast<const float4v*>(a.s + wave * D + d0);
+                    const float4v r4 = *reinterpret_cast<const float4v*>(a.s_rcp + wave * D + d0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[dt][r] = rq_div_rcp(ov[dt][r], s4[r], r4[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vmin = fminf(vmin, ov[dt][r]);
+                    vmax = fmaxf(vmax, ov[dt][r]);
+                }
+            }
+        }
+        vmin = tq_xor32(tq_xor16(vmin, false), false);
+        vmax = tq_xor32(tq_xor16(vmax, true), true);
+        if (lane < 16) {
+            ex_min[wave * 16 + tq] = vmin;
+            ex_max[wave * 16 + tq] = vmax;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (raw barrier: __syncthreads() would also wait for the loads in flight)
+        __builtin_amdgcn_s_barrier();                        // row statistics visible; every wave is done with the V tile
+        if (has_next) {
+            store_v();                                       // the next position's V rows (visible after the barrier below)
+            if (pos_n + G < npos) load_v(pos_n + G);
+        }
+        vmin = INFINITY;
+        vmax = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < H; ++w) {
+            vmin = fminf(vmin, ex_min[w * 16 + tq]);
+            vmax = fmaxf(vmax, ex_max[w * 16 + tq]);
+        }
+        float delta, zp, inv;
+        bool small;
+        vq_row_grid(vmin, vmax, 255.0f, delta, zp, small, inv);
+        if (small && tid < 16 && tq < a.T && a.status) atomicOr(a.status, VQ_ST_EPSFILL);
+        const int izx = (int)zp - 128;
+        uint32_t csum = 0;
+#pragma unroll
+        for (int dt = 0; dt < KS; ++dt) {
+            const int d0 = dt * 16 + 4 * g4;
+            if (d0 < D) {
+                uint32_t pk = 0;
+                float c4[4];
+                rq_round_group<4>(ov[dt], inv, delta, zp, c4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk = __builtin_amdgcn_cvt_pk_u8_f32(c4[r], r, pk);
+                csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
+                *reinterpret_cast<uint32_t*>(codes + tq * CROW + wave * D + d0) = pk ^ 0x80808080u;
+            }
+        }
+        const int cs = tq_isum4rows((int)csum);
+        if (lane < 16) ex_sum[wave * 16 + tq] = cs;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- codes out as whole 16-byte chunks (pad columns [C, Kp) zeroed like the row quantizers do)
+        {
+            uint8_t* xb = reinterpret_cast<uint8_t*>(a.xq) + row0 * (size_t)a.Kp;
+#pragma unroll
+            for (int j = 0; j < NCI; ++j)
+                if (cok[j]) {
+                    const int4v val = cpad[j] ? int4v{0, 0, 0, 0} : *reinterpret_cast<const int4v*>(codes + clo[j]);
+                    *reinterpret_cast<int4v*>(xb + cgo[j]) = val;
+                }
+        }
+        if (tid < 16 && tq < a.T) {
+            int rs = 0;
+#pragma unroll
+            for (int w = 0; w < H; ++w) rs += ex_sum[w * 16 + tq];
+            const size_t grow = row0 + (size_t)tq * a.S;
             a.sx[grow] = delta;
             a.zx[grow] = izx;
             a.R[grow] = rs - 128 * C - C * izx;
@@ -1326,6 +1583,273 @@ static int launch_attn32d(const AttnArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
+// attn_fwd64d_kernel (round 6): attn_fwd32d_kernel with 64 queries per wave (two 32-row blocks A / B) and two waves per
+// SIMD (<= 256 VGPRs) instead of 32 queries and four.  Every K / V^T fragment read from LDS feeds TWO MFMAs (LDS bytes per
+// MFMA halved), the QK^T chains of the two blocks interleave (no 5-deep dependent chain), and block B's softmax (VALU /
+// v_exp) is issued between block A's P.V MFMAs.  Same tile images, fragment layouts, lazy rescale and ones-column row sums;
+// per query row the arithmetic is that of attn_fwd32d_kernel (bit-identical outputs, tested).
+// ---------------------------------------------------------------------------
+template <int D, int NW = 8, int KT = 64>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd64d_kernel(AttnArgs a) {
+    static_assert(KT % 64 == 0, "key tile in 64-row DMA units");
+    constexpr int NQ = 2;
+    constexpr int KTB = (KT / 64) * Att8Cfg<D, 8>::KTILE;
+    using C = Att8Cfg<D, NW>;
+    constexpr int VRB = 192, VT = KT * VRB;
+    constexpr int KSL = C::KROW / 16, VSL = VRB / 16;
+    constexpr int NKI = KSL * (KT / 64), NVI = VSL * (KT / 64);
+    constexpr int NI = NKI + NVI, IPW = (NI + NW - 1) / NW;
+    constexpr int PF = 2;
+    static_assert(D * 2 + 2 <= VRB && C::DT * 64 <= VRB, "dims + ones column inside a row; every 32-dim tile readable");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    int qt, h, seq;
+    {
+        const int nqt = (a.Lq + 32 * NQ * NW - 1) / (32 * NQ * NW);
+        const int G = a.n_seq * a.H;
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+        const int q8 = G / 8, r8 = G % 8;
+        const int gbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        const int gcount = xcd < r8 ? q8 + 1 : q8;
+        const int pl = idx / nqt;
+        if (pl >= gcount) return;
+        const int pair = gbase + pl;
+        qt = idx - pl * nqt;
+        seq = pair / a.H;
+        h = pair - seq * a.H;
+    }
+    const int kv_len = a.Lk;
+    const half_t* kbase = a.k + (long)seq * a.kv_seq_stride + h * D;
+    const half_t* vbase = a.v + (long)seq * a.kv_seq_stride + h * D;
+    int qi[NQ];
+    bool q_ok[NQ];
+    half8 qf[NQ][C::KS];
+    float16v oacc[NQ][C::DT];
+    float m_run[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) {
+        qi[nq] = qt * (32 * NQ * NW) + wave * (32 * NQ) + nq * 32 + l31;
+        q_ok[nq] = qi[nq] < a.Lq;
+        m_run[nq] = -INFINITY;
+        const half_t* qrow = a.q + (long)seq * a.q_seq_stride + (long)(q_ok[nq] ? qi[nq] : a.Lq - 1) * a.q_tok_stride + h * D;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int d0 = ks * 16 + 8 * g;
+            if (d0 < D) qf[nq][ks] = *reinterpret_cast<const half8*>(qrow + d0);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[nq][ks][e] = (half_t)0.f;
+        }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[nq][dt][r] = 0.f;
+    }
+    const int nkt = (kv_len + KT - 1) / KT;
+    const int strideB = (int)a.kv_tok_stride * 2;
+    const unsigned nrec = kv_len > 0 ? (unsigned)(kv_len - 1) * (unsigned)strideB + D * 2 : 0u;
+    bool ok[IPW];
+    int voff[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int j = wave + NW * i;                       // wave-uniform instruction index: K tile first, then V
+        const bool isk = j < NKI;
+        const int slot = (isk ? j : j - NKI) * 64 + lane;
+        const int row = isk ? slot / KSL : slot / VSL;
+        const int piece = slot - row * (isk ? KSL : VSL);
+        ok[i] = j < NI && piece < C::CHD;
+        voff[i] = row * strideB + piece * 16;
+    }
+    auto issue = [&](int kt, int part = -1) __attribute__((always_inline)) {   // part 0: round i == 0, 1: the others, -1: all
+        const unsigned t0 = (unsigned)kt * (unsigned)KT * (unsigned)strideB;
+        const int buf = kt & 1;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int j = wave + NW * i;
+            if (j < NI && (part < 0 || (part == 0) == (i == 0))) {
+                const bool isk = j < NKI;
+                const uint8_t* b = reinterpret_cast<const uint8_t*>(isk ? kbase : vbase) + t0;
+                const unsigned long ba = (unsigned long)b;
+                const int4v rs = {(int)__builtin_amdgcn_readfirstlane((unsigned)ba),
+                                  (int)__builtin_amdgcn_readfirstlane((unsigned)(ba >> 32) & 0xffffu),
+                                  (int)__builtin_amdgcn_readfirstlane(nrec - t0), 0x00020000};
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem +
+                    (isk ? buf * KTB + j * 1024 : 2 * KTB + buf * VT + (j - NKI) * 1024));
+                if (ok[i])     // (asm, M0 and hazards: see attn_fwd32d_kernel)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff[i]), "s"(rs)
+                                 : "memory", "m0");
+            }
+        }
+    };
+    auto wg_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    for (int i = tid; i < 2 * KT * 3; i += 64 * NW) {   // pad columns of both V images: column D = 1.0, the rest 0
+        const int r = i / 3, ch = i % 3;
+        *reinterpret_cast<int4v*>(smem + 2 * KTB + r * VRB + D * 2 + ch * 16) = int4v{ch == 0 ? 0x00003c00 : 0, 0, 0, 0};
+    }
+    if (nkt > 0) issue(0);
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) asm volatile("" ::"v"(qf[nq][ks]));   // the compiler's wait for the Q loads goes HERE
+    wg_barrier();
+    const int vtr0 = (4 * g + ((lane & 15) >> 2)) * VRB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+    auto tile = [&](auto rag_tag, const int kt) __attribute__((always_inline)) {
+        constexpr bool RAG = decltype(rag_tag)::value;
+        const uint8_t* kt_ = smem + (kt & 1) * KTB + l31 * C::KROW;
+        const uint8_t* vt_ = smem + 2 * KTB + (kt & 1) * VT + vtr0;
+#pragma unroll
+        for (int sc = 0; sc < KT / 32; ++sc) {
+            float16v s[NQ];
+            const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            union VF {
+                half8 v;
+                h4_t h[2];
+            };
+            VF vf[2 * C::DT];
+            auto rdv = [&](int idx) __attribute__((always_inline)) {      // V^T fragment idx = k2 * DT + dt of this half tile
+                const int kk = 2 * sc + idx / C::DT, dt = idx % C::DT;
+                const uint8_t* vp = vt_ + (16 * kk) * VRB + dt * 64;
+                vf[idx].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp));
+                vf[idx].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(vp + 8 * VRB));
+            };
+            half8 kf[C::KS];
+            auto rdc = [&](int n) __attribute__((always_inline)) {
+                if (n < C::KS) {
+                    const int d0 = n * 16 + 8 * g;
+                    kf[n] = *reinterpret_cast<const half8*>(kt_ + sc * 32 * C::KROW + (d0 < D ? d0 : 0) * 2);
+                } else if (n - C::KS < 2 * C::DT) rdv(n - C::KS);
+            };
+#pragma unroll
+            for (int n = 0; n < PF; ++n) rdc(n);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {                       // two interleaved chains: one K fragment, two MFMAs
+                rdc(ks + PF);
+#pragma unroll
+                for (int nq = 0; nq < NQ; ++nq)
+                    s[nq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[nq][ks], ks == 0 ? zero16 : s[nq], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (sc < 2 && kt + 1 < nkt) issue(kt + 1, sc);
+            half8 pf[NQ][2];
+            float mc[NQ];
+            // decide(nq): row maxima of block nq, the lazy rescale of its O (a branch), the exponent offset.  Both blocks
+            // decide FIRST, so that what remains - expo(nq): 16 fma + 16 v_exp + 8 cvt, straight-line - can sit between MFMAs
+            auto decide = [&](int nq) __attribute__((always_inline)) {
+                if constexpr (RAG) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * KT + sc * 32 + (r & 3) + 8 * (r >> 2) + 4 * g >= kv_len) s[nq][r] = -INFINITY;
+                }
+                float mloc;
+                {
+                    float mx;   // (asm chain and the compiler-visible first read: see attn_fwd32d_kernel)
+                    const float s0 = s[nq][0] + 0.0f;
+                    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\t"
+                        "v_max3_f32 %0, %0, %8, %9\n\tv_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\t"
+                        "v_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
+                        : "=&v"(mx)
+                        : "v"(s0), "v"(s[nq][1]), "v"(s[nq][2]), "v"(s[nq][3]), "v"(s[nq][4]), "v"(s[nq][5]), "v"(s[nq][6]), "v"(s[nq][7]),
+                          "v"(s[nq][8]), "v"(s[nq][9]), "v"(s[nq][10]), "v"(s[nq][11]), "v"(s[nq][12]), "v"(s[nq][13]), "v"(s[nq][14]),
+                          "v"(s[nq][15]));
+                    const unsigned mb = __builtin_bit_cast(unsigned, mx);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                    asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(sw[0]), "v"(sw[1]));
+                }
+                if (__any((mloc - m_run[nq]) * a.c > 8.0f)) {
+                    const float m_new = fmaxf(m_run[nq], mloc);
+                    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[nq] - m_use) * a.c);
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[nq][dt][r] *= alpha;
+                    m_run[nq] = m_new;
+                }
+                mc[nq] = ((m_run[nq] == -INFINITY) ? 0.f : m_run[nq]) * a.c;
+            };
+            auto expo = [&](int nq) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {                     // plain v_fma_f32 (see attn_fwd32d_kernel)
+                    const float t0 = __builtin_fmaf(s[nq][r], a.c, -mc[nq]), t1 = __builtin_fmaf(s[nq][r + 1], a.c, -mc[nq]);
+                    pf[nq][r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(t0);
+                    pf[nq][r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t1);
+                }
+            };
+            decide(0);
+            decide(1);
+            expo(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // block A's P.V MFMAs with block B's exponentials between them (one region for the scheduler), then block B's P.V
+#pragma unroll
+            for (int idx = 0; idx < 2 * C::DT; ++idx) {
+                rdc(C::KS + idx + PF);
+                oacc[0][idx % C::DT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx].v, pf[0][idx / C::DT], oacc[0][idx % C::DT], 0, 0, 0);
+            }
+            expo(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int idx = 0; idx < 2 * C::DT; ++idx)
+                oacc[1][idx % C::DT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[idx].v, pf[1][idx / C::DT], oacc[1][idx % C::DT], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wg_barrier();
+    };
+    {
+        const int nfull = kv_len / KT;
+        int kt = 0;
+        for (; kt < nfull; ++kt) tile(std::false_type{}, kt);
+        if (kt < nkt) tile(std::true_type{}, kt);
+    }
+    constexpr int LD_T = D / 32, LD_R = D % 32;
+    constexpr int LD_G = (LD_R >> 2) & 1, LD_REG = (LD_R & 3) + 4 * (LD_R >> 3);
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) {
+        float l_run = oacc[nq][LD_T][LD_REG];
+        l_run = __shfl(l_run, l31 + 32 * LD_G);
+        const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
+        if (q_ok[nq]) {
+            half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi[nq] * a.o_tok_stride + h * D;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d = dt * 32 + 8 * rg + 4 * g;
+                    if (d < D) {
+                        half4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[nq][dt][rg * 4 + e] * inv);
+                        *reinterpret_cast<half4*>(orow + d) = ov;
+                    }
+                }
+        }
+    }
+}
+
+template <int D, int NW = 8, int KT = 64>
+static int launch_attn64d(const AttnArgs& a, hipStream_t st) {
+    constexpr int LDS = 2 * (KT / 64) * Att8Cfg<D, 8>::KTILE + 2 * KT * 192;
+    auto k = attn_fwd64d_kernel<D, NW, KT>;
+    const int nqt = (a.Lq + 64 * NW - 1) / (64 * NW), G = a.n_seq * a.H;
+    static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);  // once
+    if (e != hipSuccess) {
+        g_vq_last_hip_error = (int)e;
+        return VQ_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3(8 * ((G + 7) / 8) * nqt), dim3(64 * NW), LDS, st, a);
+    return vq_check_launch();
+}
+
+// ---------------------------------------------------------------------------
 // attn_cross32_kernel (round 4): cross attention against a SHORT key/value sequence (<= 128 keys) as attn_fwd32d_kernel
 // with the loops interchanged - K and V of ONE (sequence, head) pair are brought into LDS ONCE per workgroup (two 64-key
 // tile images, the layouts and fragment reads of attn_fwd32d_kernel: K rows KROW bytes read as ds_read_b128, V row-major
@@ -1517,7 +2041,12 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
                 mx = fmaxf(mx, s[15]);
                 const unsigned mb = __builtin_bit_cast(unsigned, mx);
                 const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-                mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+                // (the two halves are copied out of the vector FIRST: hipcc of ROCm 7.2 reads element 0 for BOTH operands of
+                //  __builtin_bit_cast(float, sw[i]) written on the vector elements directly - rounds 4-5 shipped this kernel with
+                //  mloc = the maximum over only half of the keys of a 32-key tile: still an exact softmax, the reference point
+                //  just was not the row maximum, so P could exceed the 2^8 the lazy rescale assumes; found in round 6)
+                const unsigned sw0 = sw[0], sw1 = sw[1];
+                mloc = fmaxf(__builtin_bit_cast(float, sw0), __builtin_bit_cast(float, sw1));
             }
             if (__any((mloc - m_run) * a.c > 8.0f)) {
                 const float m_new = fmaxf(m_run, mloc);
@@ -1864,6 +2393,14 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         // VQ_ATTN_NW=4 (measurement arm, round 5): four waves per workgroup - three independent workgroups per CU by LDS
         // instead of two lock-stepped groups of eight
         static const bool nw4 = getenv("VQ_ATTN_NW") && atoi(getenv("VQ_ATTN_NW")) == 4;
+#if defined(VQ_ATTN_64) && VQ_ATTN_64 > 0   // round-6 A/B builds: 64 queries per wave everywhere (1: 64-key tiles, 2: 128-key tiles,
+        if (!gen8 && a.Lq >= 512 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31))   // 3: four waves per workgroup, two workgroups per CU)
+            return VQ_ATTN_64 == 2 ? launch_attn64d<D, 8, 128>(a, st) : VQ_ATTN_64 == 3 ? launch_attn64d<D, 4, 64>(a, st) : launch_attn64d<D>(a, st);
+#else
+        // 64 queries per wave (attn_fwd64d_kernel) where a workgroup walks MANY key tiles (PixArt-Sigma's 4096-token images:
+        // 181.4 vs 188.1 us, round 6); at 1024 keys the two forms tie (111.7 vs 111.6 us) and the 32-query form stays
+        if (!gen8 && a.Lq >= 2048 && a.Lk >= 2048 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31)) return launch_attn64d<D>(a, st);
+#endif
         if (!gen8 && a.Lq >= 192 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31))
             return (nw4 && D == 72) ? launch_attn32d<D, 4>(a, st) : launch_attn32d<D>(a, st);
         return a.Lq >= 192 ? launch_attn8<D, 8>(a, st) : launch_attn8<D, 4>(a, st);
@@ -1958,6 +2495,19 @@ static int launch_temporal_quant(const TempQArgs& a, hipStream_t st) {
     }();
     const int per_cu = a.H > 8 ? 1 : (LDS > 80 * 1024 ? 1 : (LDS > 52 * 1024 ? 2 : 3));
     const int grid = npos < ncu * per_cu ? npos : ncu * per_cu;
+#ifndef VQ_TEMPORAL_V1   // (A/B builds: -DVQ_TEMPORAL_V1 keeps the round-3 kernel everywhere)
+    // H = 16 heads, 32-bit byte offsets inside a position's rows: the instruction-trimmed kernel (round 6)
+    if (a.H == 16 && a.Kp <= 2048 && (long)a.T * a.S * a.ld_in * 2 < (1l << 31) && (long)a.T * a.S * a.Kp < (1l << 31)) {
+        auto k2 = attn_temporal_quant2_kernel<D>;
+        static hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        if (e2 != hipSuccess) {
+            g_vq_last_hip_error = (int)e2;
+            return VQ_ELAUNCH;
+        }
+        hipLaunchKernelGGL(k2, dim3(grid), dim3(1024), LDS, st, a);
+        return vq_check_launch();
+    }
+#endif
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * a.H), LDS, st, a);
     return vq_check_launch();
 }
