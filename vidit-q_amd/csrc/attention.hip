@@ -1301,6 +1301,41 @@ __global__ __launch_bounds__(64 * NW, NQ == 2 ? 1 : 8 / NW) void attn_fwd8_kerne
 // ---------------------------------------------------------------------------
 typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));   // operand type of the LDS transpose read
 
+// O^T leaves the 32 x 32 matrix core with 4 consecutive dims per lane and (dt, rg) group, the partner lane (g ^ 1) holding the
+// other half of each 8-dim group: one v_permlane32_swap per dword turns two groups into 8 consecutive dims per lane - 16-byte
+// stores, 32 contiguous bytes per row and instruction instead of 16 (the store tail of a row-per-lane epilogue is bound by
+// store INSTRUCTIONS, not bytes: cdna_hip_programming.md T21).  Every lane of the wave must call this (the swaps are
+// wave-wide); `row_ok` masks the stores only.  Round 4: cross attention; round 6: the self-attention kernels too.
+template <int D, int DT>
+__device__ __forceinline__ void attn_store_rows(const float16v (&oacc)[DT], float inv, half_t* orow, int g, bool row_ok) {
+    constexpr int NG = D / 8;                           // 8-dim groups: dt = grp / 4, rg = grp % 4
+#pragma unroll
+    for (int p2 = 0; p2 < NG / 2; ++p2) {
+        const int ga = 2 * p2, gb = 2 * p2 + 1;
+        uint32_t A[2], B[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+            const h2_t ha = {(half_t)(oacc[ga / 4][(ga % 4) * 4 + 2 * w] * inv), (half_t)(oacc[ga / 4][(ga % 4) * 4 + 2 * w + 1] * inv)};
+            const h2_t hb = {(half_t)(oacc[gb / 4][(gb % 4) * 4 + 2 * w] * inv), (half_t)(oacc[gb / 4][(gb % 4) * 4 + 2 * w + 1] * inv)};
+            A[w] = __builtin_bit_cast(uint32_t, ha);
+            B[w] = __builtin_bit_cast(uint32_t, hb);
+        }
+        // swap(A, B): first result = {low lanes: A of g = 0, high lanes: B of g = 0}, second = {A of g = 1, B of g = 1}
+        const auto s0 = __builtin_amdgcn_permlane32_swap(A[0], B[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(A[1], B[1], false, false);
+        const int4v ov = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+        if (row_ok) *reinterpret_cast<int4v*>(orow + 16 * p2 + 8 * g) = ov;
+    }
+    if constexpr (NG % 2 == 1) {                        // the odd last group: 8-byte stores
+        constexpr int gl = NG - 1;
+        half4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[gl / 4][(gl % 4) * 4 + e] * inv);
+        if (row_ok) *reinterpret_cast<half4*>(orow + 8 * gl + 4 * g) = ov;
+    }
+}
+
 template <int D, int ABLD = 0, int NW = 8, int KT = 64>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_fwd32d_kernel(AttnArgs a) {
     static_assert(KT % 64 == 0, "key tile in 64-row DMA units");
@@ -1538,8 +1573,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_fwd32d_kernel(A
     float l_run = oacc[LD_T][LD_REG];
     l_run = __shfl(l_run, l31 + 32 * LD_G);
     const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
-    if (q_ok) {
-        half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi * a.o_tok_stride + h * D;
+    half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)(q_ok ? qi : a.Lq - 1) * a.o_tok_stride + h * D;
+    if constexpr (D % 8 == 0 && D >= 16) attn_store_rows<D, C::DT>(oacc, inv, orow, g, q_ok);   // 16-byte stores (round 6: 9 -> 5 per lane at D = 72)
+    else if (q_ok) {
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -1816,21 +1852,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd64d_kernel(AttnArgs a) {
         float l_run = oacc[nq][LD_T][LD_REG];
         l_run = __shfl(l_run, l31 + 32 * LD_G);
         const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
-        if (q_ok[nq]) {
-            half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)qi[nq] * a.o_tok_stride + h * D;
-#pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int d = dt * 32 + 8 * rg + 4 * g;
-                    if (d < D) {
-                        half4 ov;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[nq][dt][rg * 4 + e] * inv);
-                        *reinterpret_cast<half4*>(orow + d) = ov;
-                    }
-                }
-        }
+        half_t* orow = a.o + (long)seq * a.o_seq_stride + (long)(q_ok[nq] ? qi[nq] : a.Lq - 1) * a.o_tok_stride + h * D;
+        static_assert(D % 8 == 0 && D >= 16, "16-byte store epilogue");
+        attn_store_rows<D, C::DT>(oacc[nq], inv, orow, g, q_ok[nq]);
     }
 }
 
@@ -1848,6 +1872,10 @@ static int launch_attn64d(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(8 * ((G + 7) / 8) * nqt), dim3(64 * NW), LDS, st, a);
     return vq_check_launch();
 }
+
+#if defined(VQ_ATTN_64) || defined(VQ_ATTN_STAMPS)   // lab builds only: the opposite-phase kernel (measured slower, round 6)
+#include "../../tools/lab/attn_phased.h"
+#endif
 
 // ---------------------------------------------------------------------------
 // attn_cross32_kernel (round 4): cross attention against a SHORT key/value sequence (<= 128 keys) as attn_fwd32d_kernel
@@ -2077,39 +2105,11 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
         float l_run = oacc[LD_T][LD_REG];
         l_run = __shfl(l_run, l31 + 32 * LD_G);
         const float inv = l_run > 0.f ? __fdiv_rn(1.0f, l_run) : 0.f;
-        // O^T leaves the matrix core with 4 consecutive dims per lane and (dt, rg) group, the partner lane (g ^ 1) holding
-        // the other half of each 8-dim group: one v_permlane32_swap per dword turns two groups into 8 consecutive dims
-        // per lane - 16-byte stores, 32 contiguous bytes per row and instruction instead of 16
         const int qi = qt * (32 * NW) + wave * 32 + l31;
         const bool wave_live = qt * (32 * NW) + wave * 32 < a.Lq;      // wave-uniform
         if (wave_live) {
             half_t* orow = oseq + (long)(qi < a.Lq ? qi : a.Lq - 1) * a.o_tok_stride;
-            constexpr int NG = D / 8;                       // 8-dim groups
-#pragma unroll
-            for (int p2 = 0; p2 < NG / 2; ++p2) {
-                const int ga = 2 * p2, gb = 2 * p2 + 1;     // groups: dt = grp / 4, rg = grp % 4
-                uint32_t A[2], B[2];
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-                    const h2_t ha = {(half_t)(oacc[ga / 4][(ga % 4) * 4 + 2 * w] * inv), (half_t)(oacc[ga / 4][(ga % 4) * 4 + 2 * w + 1] * inv)};
-                    const h2_t hb = {(half_t)(oacc[gb / 4][(gb % 4) * 4 + 2 * w] * inv), (half_t)(oacc[gb / 4][(gb % 4) * 4 + 2 * w + 1] * inv)};
-                    A[w] = __builtin_bit_cast(uint32_t, ha);
-                    B[w] = __builtin_bit_cast(uint32_t, hb);
-                }
-                // swap(A, B): first result = {low lanes: A of g = 0, high lanes: B of g = 0}, second = {A of g = 1, B of g = 1}
-                const auto s0 = __builtin_amdgcn_permlane32_swap(A[0], B[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(A[1], B[1], false, false);
-                const int4v ov = {(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
-                if (qi < a.Lq) *reinterpret_cast<int4v*>(orow + 16 * p2 + 8 * g) = ov;
-            }
-            if constexpr (NG % 2 == 1) {                    // the odd last group: 8-byte stores as before
-                constexpr int gl = NG - 1;
-                half4 ov;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = (half_t)(oacc[gl / 4][(gl % 4) * 4 + e] * inv);
-                if (qi < a.Lq) *reinterpret_cast<half4*>(orow + 8 * gl + 4 * g) = ov;
-            }
+            attn_store_rows<D, C::DT>(oacc, inv, orow, g, qi < a.Lq);   // 16-byte stores (NST of them per lane, + one 8-byte store for an odd group)
             stores_behind = NST;
         } else {
             stores_behind = 0;
@@ -2394,8 +2394,10 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         // instead of two lock-stepped groups of eight
         static const bool nw4 = getenv("VQ_ATTN_NW") && atoi(getenv("VQ_ATTN_NW")) == 4;
 #if defined(VQ_ATTN_64) && VQ_ATTN_64 > 0   // round-6 A/B builds: 64 queries per wave everywhere (1: 64-key tiles, 2: 128-key tiles,
-        if (!gen8 && a.Lq >= 512 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31))   // 3: four waves per workgroup, two workgroups per CU)
-            return VQ_ATTN_64 == 2 ? launch_attn64d<D, 8, 128>(a, st) : VQ_ATTN_64 == 3 ? launch_attn64d<D, 4, 64>(a, st) : launch_attn64d<D>(a, st);
+        if (!gen8 && a.Lq >= 512 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31)) {  // 3: four waves per workgroup, two workgroups per CU; 4 / 5: opposite phases)
+            if constexpr (D >= 64 && (VQ_ATTN_64 == 4 || VQ_ATTN_64 == 5)) return launch_attn64p<D, VQ_ATTN_64 == 4 ? 3 : 4>(a, st);
+            else return VQ_ATTN_64 == 2 ? launch_attn64d<D, 8, 128>(a, st) : VQ_ATTN_64 == 3 ? launch_attn64d<D, 4, 64>(a, st) : launch_attn64d<D>(a, st);
+        }
 #else
         // 64 queries per wave (attn_fwd64d_kernel) where a workgroup walks MANY key tiles (PixArt-Sigma's 4096-token images:
         // 181.4 vs 188.1 us, round 6); at 1024 keys the two forms tie (111.7 vs 111.6 us) and the 32-query form stays
@@ -2417,6 +2419,22 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k, grid, dim3(256), C::LDS, st, a);
     return vq_check_launch();
 }
+
+#ifdef VQ_ATTN_STAMPS   // lab builds only: the phased kernel with cycle stamps (D = 72): stamps = uint32[workgroups][8 waves][16]
+extern "C" int vq_lab_attn64p_stamped(const void* q, const void* k, const void* v, void* o, int n_seq, int Lq, int Lk, int H,
+                                      long q_seq_stride, long q_tok_stride, long kv_seq_stride, long kv_tok_stride,
+                                      long o_seq_stride, long o_tok_stride, float scale, void* stamps, void* stream) {
+    AttnArgs a{(const half_t*)q, (const half_t*)k, (const half_t*)v, (half_t*)o, q_seq_stride, q_tok_stride,
+               kv_seq_stride, kv_tok_stride, o_seq_stride, o_tok_stride, nullptr, n_seq, Lq, Lk, H, scale * ATT_LOG2E};
+    constexpr int NB = VQ_ATTN_STAMPS;
+    constexpr int LDS = NB * (Att8Cfg<72, 8>::KTILE + 64 * 192);
+    auto kern = attn_fwd64p_kernel<72, NB, 1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const int nqt = (Lq + 511) / 512, G = n_seq * H;
+    hipLaunchKernelGGL(kern, dim3(8 * ((G + 7) / 8) * nqt), dim3(512), LDS, (hipStream_t)stream, a, (long long*)stamps);
+    return vq_check_launch();
+}
+#endif
 
 extern "C" int vq_attn_fwd(const void* q, const void* k, const void* v, void* o, int n_seq, int Lq, int Lk, int H,
                            int D, long q_seq_stride, long q_tok_stride, long kv_seq_stride, long kv_tok_stride,
