@@ -16,7 +16,7 @@ EXTRA="$@"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras $EXTRA > $O/stats.log 2>&1)
 pass() {  # name, counters...
   n=$1; shift
-  (cd /tmp && timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$n -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-graph --no-roofline-events $EXTRA > $O/$n.log 2>&1)
+  (cd /tmp && timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$n -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-graph --no-roofline-events --no-telemetry $EXTRA > $O/$n.log 2>&1)
 }
 pass FETCH_SIZE FETCH_SIZE
 pass WRITE_SIZE WRITE_SIZE

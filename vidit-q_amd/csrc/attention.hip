@@ -1873,6 +1873,9 @@ static int launch_attn64d(const AttnArgs& a, hipStream_t st) {
     return vq_check_launch();
 }
 
+#ifdef VQ_ATTN_STREAM_LAB   // lab builds only: the two-query-tile stream form (measured equal to the product kernel, round 6)
+#include "../../tools/lab/attn_stream.h"
+#endif
 #if defined(VQ_ATTN_64) || defined(VQ_ATTN_STAMPS)   // lab builds only: the opposite-phase kernel (measured slower, round 6)
 #include "../../tools/lab/attn_phased.h"
 #endif
@@ -2402,6 +2405,20 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         // 64 queries per wave (attn_fwd64d_kernel) where a workgroup walks MANY key tiles (PixArt-Sigma's 4096-token images:
         // 181.4 vs 188.1 us, round 6); at 1024 keys the two forms tie (111.7 vs 111.6 us) and the 32-query form stays
         if (!gen8 && a.Lq >= 2048 && a.Lk >= 2048 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31)) return launch_attn64d<D>(a, st);
+#ifdef VQ_ATTN_STREAM_LAB
+        // the two query tiles of a pair as one tile stream (attn_fwd64s_kernel) where the plain launch would be SEVERAL generations
+        // of short-lived workgroups: >= 512 tiles of 512 queries (STDiT's spatial attention: 256 pairs x 2 tiles, 16 key tiles each).
+        // VQ_ATTN_STREAM=0 keeps the 32-query form (A/B measurements).
+        const char* se = getenv("VQ_ATTN_STREAM");      // (read per call: the bit-identity test flips it inside one process)
+        const bool no_stream = se && atoi(se) == 0;
+        if constexpr (D % 8 == 0 && D >= 64) {
+            const long tiles64 = (long)a.n_seq * a.H * ((a.Lq + 511) / 512);
+            // (>= 64 D / 512 key tiles per query tile: that many tiles carry the parked O rows out; >= 4 for the Q prefetch)
+            if (!gen8 && !no_stream && !nw4 && a.Lq > 512 && a.Lk >= 64 * (64 * D * 2 / 1024) && tiles64 >= 512 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31) &&
+                (long)a.Lq * a.q_tok_stride * 2 < (1l << 31))
+                return launch_attn64s<D>(a, st);
+        }
+#endif
 #endif
         if (!gen8 && a.Lq >= 192 && (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31))
             return (nw4 && D == 72) ? launch_attn32d<D, 4>(a, st) : launch_attn32d<D>(a, st);
