@@ -221,3 +221,15 @@ def stdit_full_calib_inputs(seed: int):
     for i, n in enumerate((80, 33, 120, 57)):
         masks[i, :n] = 1
     return xs, torch.tensor([999, 721, 400, 61]), cs, masks
+
+
+def parity_floor_file():
+    """The newest committed profiles/rNN_parity_floor.json (tools/parity_floor.py: fp32 oracle vs the reference's fp32 mode at the
+    full-size golden checkpoints; its checksummed log is profiles/rNN_parity_floor_log.txt)."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = sorted((int(re.search(r"r(\d+)_parity_floor\.json$", f).group(1)), f)
+               for f in glob.glob(os.path.join(root, "profiles", "r*_parity_floor.json")))
+    return c[-1][1] if c else None

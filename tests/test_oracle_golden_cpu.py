@@ -525,7 +525,7 @@ def test_stdit_full_size_full_depth_floor_is_measured_not_argued():
     """Round 5 (asked by the round-4 review): the parity FLOOR at the headline configuration.  The fp32 oracle runs the
     SAME full-size, 28-block forward the imported reference left in stdit_full_ref.npz (~100 s on 8 cores) and its distance
     from the reference's fp32 mode is taken at blocks 0 / 13 / 27 and at the output: 3e-8, 2.3e-3, 3.3e-3, 3.4e-3 in the
-    authoring container (profiles/r05_parity_floor.json, written by tools/parity_floor.py which also covers the W4A8 and
+    authoring container (profiles/rNN_parity_floor.json, written by tools/parity_floor.py which also covers the W4A8 and
     PixArt-Sigma full-size vectors).  Two fp32 implementations of the same arithmetic, differing only in summation order,
     are 3.3e-3 apart after 28 blocks: flipped 8-bit codes at rounding ties, amplified by the contractions behind them.
     The HIP path's 4.6e-3 at block 27 is 1.4 x this floor (GPU test: <= 1.75 x), the reference's own fp16 mode 2.2 x.
@@ -546,7 +546,8 @@ def test_stdit_full_size_full_depth_floor_is_measured_not_argued():
     with torch.no_grad():
         out, blocks = sr.stdit_forward(sd, cfg, x, t, y, mask, sr.QSpec(w_bits=8), return_blocks=True)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r05_parity_floor.json")) as f:
+    from helpers import parity_floor_file
+    with open(parity_floor_file()) as f:
         rec = json.load(f)["records"]
     got = {"stdit_full/block%d" % i: (rel_l2(blocks[i][:, ::256], g["block%d" % i]),
                                        rel_l2(g["block%d_ref_fp16" % i], g["block%d" % i])) for i in (0, 13, 27)}
@@ -557,6 +558,53 @@ def test_stdit_full_size_full_depth_floor_is_measured_not_argued():
         assert e < 0.6 * r16, (k, got)
         assert 0.5 * rec[k]["oracle_fp32_vs_ref_fp32"] < e < 2.0 * rec[k]["oracle_fp32_vs_ref_fp32"], (k, e, rec[k])
         assert abs(rec[k]["ref_fp16_vs_ref_fp32"] - r16) < 1e-6 * r16 + 1e-9      # same golden file as the record
+
+
+def test_parity_floor_records_carry_a_checksummed_log():
+    """Round 6 (review item 6a/b): the floor records the GPU parity bounds read - headline, W4A8, mixed precision, PixArt-Sigma,
+    the static plan, two DDIM steps, PixArt-alpha 256 steps 1 / 5 / 10 / 20 - come from ONE script whose every run appends to
+    profiles/rNN_parity_floor_log.txt: the figures it printed, the sha256 of every golden file it read and the digest of the
+    records it left.  Here: every golden digest in the log is the committed file's, the log's last record digest is the committed
+    JSON's, every record the log printed is in the JSON with that value, and every full-size checkpoint the GPU suite asserts
+    on has a record (both legs of the bound exist).  (Re-running the script: ~30 min of CPU for all six groups.)"""
+    import hashlib
+    import json
+    import os
+    import re
+    from helpers import parity_floor_file
+    jf = parity_floor_file()
+    assert jf is not None
+    log = jf.replace(".json", "_log.txt")
+    assert os.path.exists(log), log
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = json.load(open(jf))["records"]
+    lines = open(log).read().splitlines()
+    n_gold = 0
+    for ln in lines:
+        m = re.match(r"sha256 (tests/golden/\S+) ([0-9a-f]{64})$", ln)
+        if m:
+            with open(os.path.join(root, m.group(1)), "rb") as f:
+                assert hashlib.sha256(f.read()).hexdigest() == m.group(2), m.group(1)
+            n_gold += 1
+    assert n_gold >= 6
+    digests = [ln.rsplit(" ", 1)[1] for ln in lines if ln.startswith("sha256 records(")]
+    want = hashlib.sha256(json.dumps({k: rec[k]["oracle_fp32_vs_ref_fp32"] for k in sorted(rec)}, sort_keys=True).encode()).hexdigest()
+    assert digests and digests[-1] == want
+    printed = {}
+    for ln in lines:
+        m = re.match(r"(\S+/\S+)\s+oracle (\S+)\s+reference fp16 mode (\S+)", ln)
+        if m:
+            printed[m.group(1)] = (float(m.group(2)), float(m.group(3)))
+    for k, (o, r16) in printed.items():
+        assert k in rec, k
+        assert abs(rec[k]["oracle_fp32_vs_ref_fp32"] - o) <= 6e-4 * o + 1e-12, (k, o, rec[k])      # (printed with 4 digits)
+        assert abs(rec[k]["ref_fp16_vs_ref_fp32"] - r16) <= 6e-4 * r16, (k, r16, rec[k])
+    asserted = (["stdit_full/block%d" % i for i in (0, 13, 27)] + ["stdit_full/out", "stdit_full/ddim2_final"] +
+                ["stdit_full_static/joint_t721_block27", "stdit_full_static/joint_t721_out"] +
+                ["stdit_full_w4a8/%s_%s" % (c, w) for c in ("w4a8_t721", "w4a8_mp_t300") for w in ("block27", "out")] +
+                ["sigma1024_full/block0", "sigma1024_full/block27", "sigma1024_full/out"] +
+                ["alpha256_full/" + k for k in ("call0_block0", "call0_eps", "x1", "x5", "x10", "final")])
+    assert all(k in rec and k in printed for k in asserted), [k for k in asserted if k not in rec or k not in printed]
 
 
 ATTN_KAT_CASES = [("L1024", 2, 1024, 16), ("L160", 3, 160, 4), ("L16", 64, 16, 8)]   # as tests/golden/make_golden.py

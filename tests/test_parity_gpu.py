@@ -70,14 +70,15 @@ _FLOOR = {}
 
 def parity_floor(name):
     """The MEASURED floor at a full-size checkpoint: rel-L2 of the fp32 oracle from the reference's fp32 mode on the same
-    forward (tools/parity_floor.py -> profiles/r05_parity_floor.json, CPU, committed) - what two fp32 implementations of
+    forward (tools/parity_floor.py -> profiles/rNN_parity_floor.json, CPU, committed; the newest one is read) - what two fp32 implementations of
     the same arithmetic are apart there.  None for places without a measurement."""
     if not _FLOOR:
         import json
         import os
-        f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_parity_floor.json")
+        from helpers import parity_floor_file
+        f = parity_floor_file()                        # the newest committed record (round 6: every full-size assert has one)
         _FLOOR["_"] = None
-        if os.path.exists(f):
+        if f and os.path.exists(f):
             with open(f) as fh:
                 _FLOOR.update({k: v["oracle_fp32_vs_ref_fp32"] for k, v in json.load(fh)["records"].items()})
     return _FLOOR.get(name)
