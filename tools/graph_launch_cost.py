@@ -16,7 +16,15 @@ def capture(n, branches=1):
     s2 = torch.cuda.Stream()
     with torch.cuda.stream(s):
         with torch.cuda.graph(g, stream=s):
-            if branches == 2:
+            if branches == 3:                       # a long chain with ONE short side branch at its head (2 nodes)
+                s2.wait_stream(s)
+                with torch.cuda.stream(s2):
+                    y.add_(1.0)
+                    y.add_(1.0)
+                for _ in range(n - 2):
+                    x.add_(1.0)
+                s.wait_stream(s2)
+            elif branches == 2:
                 s2.wait_stream(s)
                 with torch.cuda.stream(s2):
                     for _ in range(n // 2):
@@ -32,7 +40,7 @@ def capture(n, branches=1):
 
 print("| nodes | branches | host time of replay(), empty queue (median of 9) | per node | GPU time of the graph | host time with 8 replays queued behind each other |")
 print("|---|---|---|---|---|---|")
-for n, br in ((1, 1), (10, 1), (100, 1), (500, 1), (1000, 1), (1000, 2), (2000, 2)):
+for n, br in ((1, 1), (10, 1), (100, 1), (500, 1), (1000, 1), (1000, 2), (2000, 2), (1000, 3)):
     g = capture(n, br)
     for _ in range(3):
         g.replay()
@@ -57,3 +65,42 @@ for n, br in ((1, 1), (10, 1), (100, 1), (500, 1), (1000, 1), (1000, 2), (2000, 
     torch.cuda.synchronize()
     h = sorted(host)[4]
     print("| %d | %d | %.3f ms | %.2f us | %.3f ms | %.3f ms per replay |" % (n, br, h * 1e3, h / n * 1e6, sorted(gpu)[4], tq * 1e3))
+
+# two single-chain graphs replayed CONCURRENTLY on two streams (what one two-branch graph expresses)
+z = torch.zeros(64, device=dev)
+
+
+def chain(buf, n, stream):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        with torch.cuda.graph(g, stream=stream):
+            for _ in range(n):
+                buf.add_(1.0)
+    return g
+
+
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+for n in (500, 1000):
+    ga, gb = chain(x, n, sa), chain(z, n, sb)
+    host, gpu = [], []
+    for it in range(12):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream()
+        t0 = time.perf_counter()
+        e0.record()
+        sa.wait_stream(cur)
+        sb.wait_stream(cur)
+        with torch.cuda.stream(sa):
+            ga.replay()
+        with torch.cuda.stream(sb):
+            gb.replay()
+        cur.wait_stream(sa)
+        cur.wait_stream(sb)
+        t1 = time.perf_counter()
+        e1.record()
+        torch.cuda.synchronize()
+        if it >= 3:
+            host.append(t1 - t0)
+            gpu.append(e0.elapsed_time(e1))
+    print("| 2 x %d | two single-chain graphs on two streams | %.3f ms | %.2f us | %.3f ms | - |" % (n, sorted(host)[4] * 1e3, sorted(host)[4] / (2 * n) * 1e6, sorted(gpu)[4]))
