@@ -709,9 +709,6 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_fast_kernel(
 
 // LN + modulate + ONE un-smoothed quantizer, two rows per wave (same reasoning as rowquant_half_kernel; this
 // kernel has five per-row reductions and four IEEE divisions / a square root per row).
-#ifndef VQ_LN_LEAN
-#define VQ_LN_LEAN 1        // (0: the round-5 form with the row in fp32 registers - A/B builds)
-#endif
 #define RQH_REDUCE2(T_, OP_, v_)                                                                        \
     {                                                                                                   \
         VQ_DPP_STEP(T_, OP_, v_, 0xB1);                                                                 \
@@ -727,14 +724,8 @@ __global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_fast_kernel(
     }
 // XM: also store the modulated activation as fp16 (the t2i final layer's LayerNorm + modulate in front of a Linear that
 // quantizes its own input: for B = 2 that call used to fall to the generic kernel, 74 us per PixArt-Sigma step)
-// LEAN (round 6): the row stays PACKED (fp16, NIT x 2 registers) and the modulated value u is computed twice - once for the
-// row's min / max, once for its codes, the modulation vectors re-read from L1 - instead of held as NIT x 4 fp32 registers next
-// to 8 x NIT of vector loads the compiler hoists: 82 -> <= 64 VGPRs, i.e. eight waves per SIMD instead of five.  A launch of
-// 16384 rows is 8192 waves = 8 per SIMD: at five resident the last 3 / 8 of them start when a slot frees (1.6 generations of
-// a latency-bound kernel: 15.9 us at 3.57 TB/s against rowquant_half_kernel's 12.2 us at 4.63 TB/s with 60 registers).  Same
-// operations in the same order per element (codes bit-identical, tested against the oracle); residency beat prefetch again.
-template <int NIT, bool PAIR = false, bool XM = false, bool LEAN = false>   // PAIR: see rowquant_half_kernel; shift / scale [2, C], one row per sample
-__global__ __launch_bounds__(RQF_THREADS, LEAN ? 8 : 1) void ln_modulate_rowquant_half_kernel(
+template <int NIT, bool PAIR = false, bool XM = false>   // PAIR: see rowquant_half_kernel; shift / scale [2, C], one row per sample
+__global__ __launch_bounds__(RQF_THREADS) void ln_modulate_rowquant_half_kernel(
     const half_t* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ scale, float ln_eps,
     int8_t* __restrict__ xq, float* __restrict__ sx, int32_t* __restrict__ zx, int32_t* __restrict__ R, int n_tok,
     int n_bits, int32_t* status, half_t* __restrict__ xm = nullptr) {
@@ -756,93 +747,6 @@ __global__ __launch_bounds__(RQF_THREADS, LEAN ? 8 : 1) void ln_modulate_rowquan
     const float invC = 1.0f / (float)C;
     const half_t* row = x + (size_t)tok * C + hl * 4;
 
-    if constexpr (LEAN) {
-        static_assert(!XM, "the lean form recomputes u instead of keeping it");
-        half4 hx[NIT];
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            hx[i] = *reinterpret_cast<const half4*>(row + i * 128);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sum += (float)hx[i][e];
-        }
-        // the packed row is made opaque between the passes: otherwise the 36 conversions to fp32 are common subexpressions of
-        // all four passes and stay live - the register set this form exists to avoid
-        auto opaque_row = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) asm volatile("" : "+v"(hx[i]));
-        };
-        RQH_REDUCE2(float, vq_addf, sum)
-        const float mu = sum * invC;
-        opaque_row();
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = (float)hx[i][e] - mu;
-                sq += d * d;
-            }
-        RQH_REDUCE2(float, vq_addf, sq)
-        const float rstd = __fdiv_rn(1.0f, __fsqrt_rn(sq * invC + ln_eps));
-        opaque_row();
-        auto modulated = [&](int i, float (&u)[4]) __attribute__((always_inline)) {
-            const float4v sc = *reinterpret_cast<const float4v*>(scale + i * 128 + hl * 4);
-            const float4v sh = *reinterpret_cast<const float4v*>(shift + i * 128 + hl * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float y = ((float)hx[i][e] - mu) * rstd;
-                u[e] = y * (1.0f + sc[e]) + sh[e];
-            }
-        };
-        // (the scheduler would hoist all 2 x NIT vector loads of a pass to its top - 72 registers - and spill: a scheduling
-        //  barrier every GRP chunks keeps 2 x GRP loads in flight)
-        constexpr int GRP = 2;
-        float vmin = INFINITY, vmax = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            float u[4];
-            modulated(i, u);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vmin = fminf(vmin, u[e]);
-                vmax = fmaxf(vmax, u[e]);
-            }
-            if (i % GRP == GRP - 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        RQH_REDUCE2(float, fminf, vmin)
-        RQH_REDUCE2(float, fmaxf, vmax)
-        if constexpr (PAIR) {
-            vmin = fminf(vmin, __shfl_xor(vmin, 32));
-            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
-        }
-        float delta, zp;
-        bool small;
-        float inv;
-        vq_row_grid(vmin, vmax, qmax, delta, zp, small, inv);
-        if (small && hl == 0 && live && status) atomicOr(status, VQ_ST_EPSFILL);
-        const int izx = (int)zp - cx;
-        int8_t* qrow = xq + (size_t)tok * C + hl * 4;
-        uint32_t csum = 0;
-        asm volatile("" ::: "memory");                 // the vectors are READ AGAIN below (not kept live across the reductions)
-        opaque_row();
-        RQ_BY_WIDTH(qmax, _Pragma("unroll") for (int i = 0; i < NIT; ++i) {
-            float u[4];
-            modulated(i, u);
-            const uint32_t pk = rq_quant4<SAT8_>(u, inv, delta, zp, qmax);
-            csum = __builtin_amdgcn_sad_u8(pk, 0u, csum);
-            if (live) *reinterpret_cast<uint32_t*>(qrow + i * 128) = pk ^ flip;
-            if (i % GRP == GRP - 1) __builtin_amdgcn_sched_barrier(0);
-        })
-        int cs = (int)csum;
-        RQH_REDUCE2(int, vq_addi, cs)
-        if (hl == 0 && live) {
-            sx[tok] = delta;
-            zx[tok] = izx;
-            R[tok] = cs - cx * C - C * izx;
-        }
-        return;
-    }
     float v[NIT][4];
     float sum = 0.f;
 #pragma unroll
@@ -1361,7 +1265,7 @@ bool vq_lnq_pair_fast(const half_t* x, const float* shift, const float* scale, f
         hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, true, true>), g2, dim3(RQF_THREADS), 0, st, x, shift,   \
                            scale, eps, xq, sx, zx, R, n_tok, n_bits, status, xm);                                     \
     else                                                                                                              \
-        hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, true, false, VQ_LN_LEAN != 0>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
+        hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, true>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps, \
                            xq, sx, zx, R, n_tok, n_bits, status, (half_t*)nullptr)
     switch (C / 128) {
         case 6: LNP_GO(6); break;
@@ -1469,8 +1373,8 @@ bool vq_lnq_fast(const half_t* x, const float* shift, const float* scale, float 
     if (n_out == 1 && !(s && s[0]) && !xm && Kp == C && (C == 1152 || C == 1024 || C == 1280 || C == 768) && n_tok >= 2) {
         dim3 g2((n_tok + 2 * RQF_WAVES - 1) / (2 * RQF_WAVES));
 #define LNH_GO(N_)                                                                                              \
-    hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_, false, false, VQ_LN_LEAN != 0>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps,  \
-                       xq[0], sx[0], zx[0], R[0], n_tok, n_bits, status, (half_t*)nullptr)
+    hipLaunchKernelGGL((ln_modulate_rowquant_half_kernel<N_>), g2, dim3(RQF_THREADS), 0, st, x, shift, scale, eps,  \
+                       xq[0], sx[0], zx[0], R[0], n_tok, n_bits, status)
         switch (C / 128) {
             case 6: LNH_GO(6); break;
             case 8: LNH_GO(8); break;
