@@ -1009,6 +1009,31 @@ def alpha256_full():
     npz("alpha256_full_ref.npz", **out)
 
 
+def dpm_solver_modes():
+    """Round 6: every mode of the reference's DPM_Solver.sample (dpm_solver_sigma.py:1069-1279) the t2i script does NOT select -
+    multistep order 3, the singlestep schedules, singlestep_fixed, the adaptive solver, the logSNR / quadratic spacings, 'taylor',
+    denoise_to_zero, t_start / t_end - through the reference's own DPMS_sigma wrapper (dpmsolver++, cfg 4.5, one batched
+    uncond | cond call) on the analytic noise model of tests/helpers.py.  Final latents + the number of model calls."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import importlib
+    from helpers import DPM_MODE_CASES, dpm_mode_inputs, dpm_mode_model
+    ref_import.load_t2i()
+    dps = importlib.import_module("diffusion.dpm_solver_sigma")
+    x, cond, null = dpm_mode_inputs()
+    out = {}
+    for name, kw in DPM_MODE_CASES:
+        calls = [0]
+
+        def fwd(x_, t_, y_, **k):
+            calls[0] += 1
+            return dpm_mode_model(x_, t_, y_)
+        solver = dps.DPMS_sigma(fwd, condition=cond, uncondition=null, cfg_scale=4.5, model_kwargs={})
+        out[name] = solver.sample(x.clone(), **kw).float()
+        out[name + "_calls"] = np.array(calls[0])
+        print("dpm_solver_modes", name, calls[0], "calls", flush=True)
+    npz("dpm_solver_modes.npz", **out)
+
+
 STDIT_FULL_SEED = 5501
 
 
@@ -1416,6 +1441,8 @@ def main():
             xl_depth6_pixart()
         if want("alpha256_full"):
             alpha256_full()
+        if want("dpm_modes"):
+            dpm_solver_modes()
         if "sigma1024_full" in only:        # ~6 minutes of CPU: only when asked for by name
             sigma1024_full()
 

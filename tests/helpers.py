@@ -233,3 +233,45 @@ def parity_floor_file():
     c = sorted((int(re.search(r"r(\d+)_parity_floor\.json$", f).group(1)), f)
                for f in glob.glob(os.path.join(root, "profiles", "r*_parity_floor.json")))
     return c[-1][1] if c else None
+
+
+# ---- DPM-Solver modes (round 6): an analytic noise model so that the solver alone is what the fixture pins
+DPM_MODE_CASES = [   # name, kwargs of .sample()
+    ("multistep3_time_uniform_20", dict(steps=20, order=3, skip_type="time_uniform", method="multistep")),
+    ("multistep3_logsnr_9", dict(steps=9, order=3, skip_type="logSNR", method="multistep")),
+    ("multistep2_quadratic_10", dict(steps=10, order=2, skip_type="time_quadratic", method="multistep")),
+    ("multistep2_taylor_8", dict(steps=8, order=2, skip_type="time_uniform", method="multistep", solver_type="taylor")),
+    ("multistep3_no_lower_final_7", dict(steps=7, order=3, skip_type="time_uniform", method="multistep", lower_order_final=False)),
+    ("multistep1_12", dict(steps=12, order=1, skip_type="time_uniform", method="multistep")),
+    ("singlestep3_logsnr_20", dict(steps=20, order=3, skip_type="logSNR", method="singlestep")),
+    ("singlestep3_time_uniform_18", dict(steps=18, order=3, skip_type="time_uniform", method="singlestep")),
+    ("singlestep3_time_uniform_19", dict(steps=19, order=3, skip_type="time_uniform", method="singlestep")),
+    ("singlestep3_taylor_12", dict(steps=12, order=3, skip_type="time_uniform", method="singlestep", solver_type="taylor")),
+    ("singlestep2_logsnr_11", dict(steps=11, order=2, skip_type="logSNR", method="singlestep")),
+    ("singlestep2_taylor_quadratic_10", dict(steps=10, order=2, skip_type="time_quadratic", method="singlestep", solver_type="taylor")),
+    ("singlestep1_time_uniform_6", dict(steps=6, order=1, skip_type="time_uniform", method="singlestep")),
+    ("singlestep_fixed3_12", dict(steps=12, order=3, skip_type="logSNR", method="singlestep_fixed")),
+    ("singlestep_fixed2_denoise_10", dict(steps=10, order=2, skip_type="time_uniform", method="singlestep_fixed", denoise_to_zero=True)),
+    ("adaptive2", dict(order=2, method="adaptive")),
+    ("adaptive3_tight", dict(order=3, method="adaptive", atol=0.002, rtol=0.02)),
+    ("multistep2_window", dict(steps=6, order=2, skip_type="time_uniform", method="multistep", t_start=0.8, t_end=0.05)),
+]
+
+
+def dpm_mode_inputs(seed=77):
+    """Latent, condition / null condition of the analytic noise model of the DPM-Solver mode fixtures."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    cond = torch.randn(2, 1, 6, 16, generator=g)
+    null = torch.randn(2, 1, 6, 16, generator=g) * 0.5
+    return x, cond, null
+
+
+def dpm_mode_model(x, t, y, **kw):
+    """eps(x, t, y): smooth in x, t and the condition - any solver error shows, no network needed.
+    (t is the model-input time in [0, 1000); y [n, 1, L, C].)"""
+    import torch
+    w = torch.cos(t.float() * (3.0 / 1000.0)).reshape(-1, 1, 1, 1)
+    c = y.float().mean(dim=(1, 2, 3)).reshape(-1, 1, 1, 1)
+    return 0.35 * w * x + 0.2 * torch.tanh(x * 0.5 + c) + 0.1 * c

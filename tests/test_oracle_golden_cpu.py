@@ -560,6 +560,34 @@ def test_stdit_full_size_full_depth_floor_is_measured_not_argued():
         assert abs(rec[k]["ref_fp16_vs_ref_fp32"] - r16) < 1e-6 * r16 + 1e-9      # same golden file as the record
 
 
+def test_dpm_solver_modes_against_the_reference():
+    """Round 6 (review "missing" item 4): every mode of the reference's DPM_Solver.sample the t2i script does not select -
+    multistep order 3, the singlestep schedules (orders 1-3, every remainder of steps mod order), singlestep_fixed, the
+    adaptive solver (orders 2 / 3), logSNR / quadratic spacings, 'taylor', denoise_to_zero, t_start / t_end - against
+    final latents the imported reference produced through its own DPMS_sigma wrapper on the analytic noise model of
+    tests/helpers.py (tests/golden/make_golden.py::dpm_solver_modes).  Same number of model calls; fp32 scalars on the host as
+    the reference computes them, so the latents agree to fp32 rounding of ~20 dependent steps."""
+    from helpers import DPM_MODE_CASES, dpm_mode_inputs, dpm_mode_model
+    from viditq_amd.t2i import DPMS_sigma
+    g = load_npz("dpm_solver_modes.npz")
+    x, cond, null = dpm_mode_inputs()
+    for name, kw in DPM_MODE_CASES:
+        calls = [0]
+
+        def fwd(x_, t_, y_, **k):
+            calls[0] += 1
+            return dpm_mode_model(x_, t_, y_)
+        got = DPMS_sigma(fwd, condition=cond, uncondition=null, cfg_scale=4.5, model_kwargs={}).sample(x.clone(), **kw)
+        ref = g[name]
+        assert calls[0] == int(g[name + "_calls"]), (name, calls[0], int(g[name + "_calls"]))
+        assert rel_l2(got, ref) < 2e-5, (name, rel_l2(got, ref))
+    # the mode the script runs is unchanged by the extension (multistep / order 2 / time_uniform): a refusal became a result
+    with pytest.raises(ValueError):
+        DPMS_sigma(dpm_mode_model, cond, null, 4.5).sample(x.clone(), steps=4, order=4)
+    with pytest.raises(ValueError):
+        DPMS_sigma(dpm_mode_model, cond, null, 4.5).sample(x.clone(), steps=4, method="heun")
+
+
 def test_parity_floor_records_carry_a_checksummed_log():
     """Round 6 (review item 6a/b): the floor records the GPU parity bounds read - headline, W4A8, mixed precision, PixArt-Sigma,
     the static plan, two DDIM steps, PixArt-alpha 256 steps 1 / 5 / 10 / 20 - come from ONE script whose every run appends to
