@@ -19,15 +19,48 @@ from .stdit_ref import QSpec, attention_core, cross_attention, qlinear, timestep
 T2I_FP_LAYERS = ("x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder")
 
 
-def pixart_block(sd, i, x, y, t0, y_lens, H, spec: QSpec, t_id=0):
+def kv_downsample(sd, prefix, tns, hw, sr, sampling):
+    """AttentionKVCompress.downsample_2d (PixArt_blocks.py:99-124): the key / value tokens [B, N, C] of an hh x ww grid reduced
+    by `sr` per axis - 'uniform_every': every sr-th TOKEN; 'uniform': every sr-th row and column; 'ave': nearest-neighbour
+    interpolation by 1 / sr (for an integer factor the same picks as 'uniform', despite the name); 'conv': the depthwise
+    `sr` convolution (kernel = stride = sr) followed by the LayerNorm `norm`."""
+    B, N, C = tns.shape
+    if sampling == "uniform_every":
+        return tns[:, ::sr]
+    hh, ww = hw
+    g = tns.reshape(B, hh, ww, C).permute(0, 3, 1, 2)
+    if sampling == "ave":
+        g = F.interpolate(g, scale_factor=1 / sr, mode="nearest").permute(0, 2, 3, 1)
+    elif sampling == "uniform":
+        g = g[:, :, ::sr, ::sr].permute(0, 2, 3, 1)
+    elif sampling == "conv":
+        g = F.conv2d(g, sd[prefix + ".sr.weight"].float(), sd[prefix + ".sr.bias"].float(), stride=sr, groups=C)
+        g = g.reshape(B, C, -1).permute(0, 2, 1)
+        g = F.layer_norm(g, (C,), sd[prefix + ".norm.weight"].float(), sd[prefix + ".norm.bias"].float())
+    else:
+        raise ValueError(sampling)
+    return g.reshape(B, int(hh / sr) * int(ww / sr), C)
+
+
+def pixart_block(sd, i, x, y, t0, y_lens, H, spec: QSpec, t_id=0, hw=None, kv=None, qk_norm=False):
+    """``kv``: None or dict(sampling, sr, layers) - key / value compression of the blocks in ``layers``; ``qk_norm``: LayerNorm
+    (over all C channels, affine) on q and k before the heads are split (PixArt_blocks.py:135-146)."""
     p = "blocks.%d" % i
     B, N, C = x.shape
     D = C // H
     mods = (sd[p + ".scale_shift_table"].float()[None] + t0.float().reshape(B, 6, -1)).chunk(6, dim=1)
     shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mods
     xm = fq.t2i_modulate(fq.layernorm_noaffine(x), shift_msa, scale_msa)
-    qkv = qlinear(sd, p + ".attn.qkv", xm, spec, t_id).reshape(B, N, 3, H, D)
-    o = attention_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5).reshape(B, N, C)
+    qkv = qlinear(sd, p + ".attn.qkv", xm, spec, t_id).reshape(B, N, 3, C)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    if qk_norm:
+        q = F.layer_norm(q, (C,), sd[p + ".attn.q_norm.weight"].float(), sd[p + ".attn.q_norm.bias"].float())
+        k = F.layer_norm(k, (C,), sd[p + ".attn.k_norm.weight"].float(), sd[p + ".attn.k_norm.bias"].float())
+    if kv is not None and i in kv["layers"] and kv["sr"] > 1:
+        hw_ = hw if hw is not None else (int(N ** 0.5), int(N ** 0.5))
+        k = kv_downsample(sd, p + ".attn", k, hw_, kv["sr"], kv["sampling"])
+        v = kv_downsample(sd, p + ".attn", v, hw_, kv["sr"], kv["sampling"])
+    o = attention_core(q.reshape(B, N, H, D), k.reshape(B, -1, H, D), v.reshape(B, -1, H, D), D ** -0.5).reshape(B, N, C)
     x = x + gate_msa * qlinear(sd, p + ".attn.proj", o, spec, t_id)
     x = x + cross_attention(sd, p + ".cross_attn", x, y, y_lens, H, spec, t_id)
     h = qlinear(sd, p + ".mlp.fc1", fq.t2i_modulate(fq.layernorm_noaffine(x), shift_mlp, scale_mlp), spec, t_id)
@@ -36,7 +69,7 @@ def pixart_block(sd, i, x, y, t0, y_lens, H, spec: QSpec, t_id=0):
 
 def pixart_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, pos_embed: torch.Tensor, t_id=None,
                    return_blocks: bool = False):
-    """cfg: dict(H, depth, patch, out_ch).  ``pos_embed`` [1, N, C] as the model computes it (MS) or holds it
+    """cfg: dict(H, depth, patch, out_ch[, kv=dict(sampling, sr, layers), qk_norm]).  ``pos_embed`` [1, N, C] as the model computes it (MS) or holds it
     (alpha: sd['pos_embed']).  ``t_id``: QuantModel pushes timestep[0] to every layer (quant_model.py:347)."""
     H, depth, p_ = cfg["H"], cfg["depth"], cfg["patch"]
     if t_id is None:
@@ -61,7 +94,7 @@ def pixart_forward(sd, cfg: dict, x, timestep, y, mask, spec: QSpec, pos_embed: 
         yy = yy.squeeze(1).reshape(1, -1, C)
     blocks = []
     for i in range(depth):
-        x = pixart_block(sd, i, x, yy, t0, y_lens, H, spec, t_id)
+        x = pixart_block(sd, i, x, yy, t0, y_lens, H, spec, t_id, hw=(hh, ww), kv=cfg.get("kv"), qk_norm=cfg.get("qk_norm", False))
         if return_blocks:
             blocks.append(x.clone())
     shift, scale = (sd["final_layer.scale_shift_table"].float()[None] + t[:, None]).chunk(2, dim=1)

@@ -1009,6 +1009,68 @@ def alpha256_full():
     npz("alpha256_full_ref.npz", **out)
 
 
+def tiny_pixart_kvcompress():
+    """Round 6 (review "missing" item 3): PixArt's key / value compression and q / k LayerNorm (PixArt_blocks.py:63-160) from
+    the imported reference - PixArtMS, hidden 64, depth 2, 4 heads, 8 x 8 tokens, qk_norm ON, both blocks compressed by 2 -
+    for every `sampling` ('conv', 'ave', 'uniform', 'uniform_every'): the FP forward; for the three samplings the reference
+    can QUANTIZE (its QuantModel wraps the depthwise `sr` conv of 'conv' as a QuantAttnLinearImg and dies in its forward) the
+    W8A8 forwards at B = 2 and B = 1 in fp32 mode and fp16 mode.  One seeded state dict (the 'conv' model's: a superset)."""
+    R = ref_import.load_t2i()
+    out = {}
+    sd = None
+    g = torch.Generator().manual_seed(41)
+    x = h(torch.randn(2, 4, 16, 16, generator=g))
+    y = h(torch.randn(2, 1, 12, 32, generator=g) * 0.5)
+    mask = torch.zeros(2, 12, dtype=torch.int64)
+    mask[0, :7] = 1
+    mask[1, :12] = 1
+    t = torch.tensor([300, 300])
+    out["x"], out["y"], out["mask"], out["t"] = x, y, mask, t
+    for samp in ("conv", "ave", "uniform", "uniform_every"):
+        torch.manual_seed(40)
+        m = R.PixArtMS(input_size=16, depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32, qk_norm=True,
+                       kv_compress_config={"sampling": samp, "scale_factor": 2, "kv_compress_layer": [0, 1]})
+        if sd is None:                                   # the 'conv' model first: every key any sampling has
+            gw = torch.Generator().manual_seed(42)
+            with torch.no_grad():
+                for n, p_ in m.named_parameters():
+                    if p_.abs().sum() == 0:
+                        p_.copy_(torch.randn(p_.shape, generator=gw) * 0.02)
+                    elif ".attn.sr.weight" in n or "_norm.weight" in n or ".attn.norm.weight" in n:
+                        p_.add_(torch.randn(p_.shape, generator=gw) * 0.05)     # not the constant initialisation
+                for p_ in m.parameters():
+                    p_.copy_(h(p_))
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            for k, v in sd.items():
+                out["sd/" + k] = v
+        else:
+            missing = m.load_state_dict(sd, strict=False)
+            assert not missing.missing_keys, missing
+        m.eval()
+        with torch.no_grad():
+            out["fp_" + samp] = m(x, t.float(), y, mask=mask)
+            if samp == "conv":
+                continue
+            qnn = R.QuantModel(m, ref_import.wq_cfg(8), ref_import.aq_cfg(T=1, S=64, n_prompt=12), model_type="pixart")
+            qnn.set_module_name_for_quantizer(qnn.model)
+            qnn.fp_layer_list = list(PIX_FP)
+            qnn.set_quant_state(True, False)
+            qnn(x, t, y, mask=mask)
+            qnn.set_quant_init_done("weight")
+            qnn.set_quant_init_done("activation")
+            qnn.set_quant_state(True, True)
+            out["w8a8_" + samp] = qnn(x, t, y, mask=mask)
+            out["w8a8_b1_" + samp] = qnn(x[:1], t[:1], y[:1], mask=mask[:1])
+            q16 = _half_copy(qnn)
+            out["w8a8_%s_ref_fp16" % samp] = q16(x.half(), t, y.half(), mask=mask).float()
+            if "qp_done" not in out:
+                _qp(out, "qp", qnn)
+                out["qp_done"] = np.array(1)
+    from diffusion.model.nets.PixArt import get_2d_sincos_pos_embed
+    out["pos_embed"] = torch.from_numpy(get_2d_sincos_pos_embed(64, (8, 8), pe_interpolation=1.0, base_size=8)).float()[None]
+    npz("tiny_pixart_kvcompress.npz", **out)
+
+
 def dpm_solver_modes():
     """Round 6: every mode of the reference's DPM_Solver.sample (dpm_solver_sigma.py:1069-1279) the t2i script does NOT select -
     multistep order 3, the singlestep schedules, singlestep_fixed, the adaptive solver, the logSNR / quadratic spacings, 'taylor',
@@ -1443,6 +1505,8 @@ def main():
             alpha256_full()
         if want("dpm_modes"):
             dpm_solver_modes()
+        if want("kvcompress"):
+            tiny_pixart_kvcompress()
         if "sigma1024_full" in only:        # ~6 minutes of CPU: only when asked for by name
             sigma1024_full()
 

@@ -382,6 +382,65 @@ def test_tiny_pixart_w8a8_fused_path(dev, ops, parity):
     assert rel_l2(qnn(x, t, y, mask=mask).cpu().float(), g["fp"]) < 3e-3
 
 
+@pytest.mark.parametrize("samp", ["conv", "ave", "uniform", "uniform_every"])
+def test_tiny_pixart_kv_compression_and_qk_norm(dev, ops, parity, samp):
+    """Round 6 (review "missing" item 3): PixArt's key / value compression (factor 2 in both blocks) and q / k LayerNorm
+    (PixArt_blocks.py:63-160) through QuantModel(model_type='pixart') against the imported reference
+    (make_golden.py::tiny_pixart_kvcompress): the FP forward of every sampling; for the three samplings the reference can
+    quantize, the fused W8A8 route (the HIP attention with 64 queries x 16 keys behind torch's LayerNorm / token picks) at
+    B = 2 and B = 1, not further from the fp32 reference than 1.25 x its own fp16 mode.  'conv': a quantized `attn.sr` raises
+    (the reference dies there too); with 'attn.sr' on the FP list the fused route runs."""
+    import viditq_amd  # noqa
+    from viditq_amd.qdiff.models import QuantModel
+    from viditq_amd.qdiff.quantizer import BaseQuantizer
+    from viditq_amd.t2i import PixArtMS
+    g = load_npz("tiny_pixart_kvcompress.npz")
+    m = PixArtMS(input_size=16, depth=2, hidden_size=64, num_heads=4, model_max_length=12, caption_channels=32, qk_norm=True,
+                 kv_compress_config={"sampling": samp, "scale_factor": 2, "kv_compress_layer": [0, 1]}, dtype=torch.float16)
+    res = m.load_state_dict(state_dict_of(g), strict=False)
+    assert not res.missing_keys and (samp != "conv" or not res.unexpected_keys)
+    m = m.half().to(dev).eval()
+    wq, aq = _cfgs(8)
+    aq["n_spatial_token"], aq["n_temporal_token"] = 64, 1
+    qnn = QuantModel(m, wq, aq, model_type="pixart")
+    qnn.set_module_name_for_quantizer(qnn.model)
+    fp_list = ["x_embedder", "t_embedder", "t_block", "y_embedder", "csize_embedder", "ar_embedder"]
+    qnn.fp_layer_list = list(fp_list)
+    x, y, mask, t = g["x"].to(dev), g["y"].half().to(dev), g["mask"].to(dev), g["t"].to(dev)
+    qnn.set_quant_state(False, False)
+    e_fp = rel_l2(qnn(x, t, y, mask=mask).cpu().float(), g["fp_" + samp])
+    parity["tiny_pixart_kvcompress/fp_" + samp] = {"vs_ref_fp32": e_fp}
+    assert e_fp < 3e-3, e_fp                                            # FP model, fp16 storage
+    qp = quant_params_of(g)
+    full = {mod.module_name: [qp.get(mod.module_name, {}), {}] for mod in qnn.model.modules() if isinstance(mod, BaseQuantizer)}
+    qnn.set_quant_params_dict(full)                  # (no grids for `attn.sr`: the reference never gets as far as making them)
+    if samp == "conv":
+        qnn.set_quant_init_done("weight")
+        qnn.set_quant_init_done("activation")
+        qnn.set_quant_state(True, True)
+        with pytest.raises(NotImplementedError):
+            qnn(x, t, y, mask=mask)
+        qnn.fp_layer_list = fp_list + ["attn.sr"]
+        qnn.set_quant_state(True, True)
+        assert all(b.fused_ok() for b in qnn.model.blocks)
+        out = qnn(x, t, y, mask=mask).cpu().float()
+        assert torch.isfinite(out).all() and rel_l2(out, g["fp_conv"]) < 0.08          # W8A8 beside an FP compression
+        return
+    qnn.set_quant_init_done("weight")
+    qnn.set_quant_init_done("activation")
+    qnn.set_quant_state(True, True)
+    assert all(b.fused_ok() for b in qnn.model.blocks)
+    assert not qnn.model.blocks[0].attn.plain
+    out = qnn(x, t, y, mask=mask).cpu().float()
+    out1 = qnn(x[:1], t[:1], y[:1], mask=mask[:1]).cpu().float()
+    drift = rel_l2(g["w8a8_%s_ref_fp16" % samp], g["w8a8_" + samp])
+    e, e1 = rel_l2(out, g["w8a8_" + samp]), rel_l2(out1, g["w8a8_b1_" + samp])
+    parity["tiny_pixart_kvcompress/w8a8_" + samp] = {"vs_ref_fp32": e, "ref_fp16_vs_ref_fp32": drift, "b1_vs_ref_fp32": e1}
+    assert e < 1.25 * drift + 1e-4, (e, drift)
+    assert e1 < 1.25 * drift + 1e-3, (e1, drift)
+    assert qnn.check_status() == 0
+
+
 def test_ptq_calibrate_pixart_reproduces_reference_quant_params(dev, ops, tmp_path):
     """ptq.calibrate_pixart (the t2i script's order: FP forward, weight forward, FP layer list) must produce the
     weight grids the golden generator obtained from the REFERENCE classes with the same sequence, and a model

@@ -560,6 +560,29 @@ def test_stdit_full_size_full_depth_floor_is_measured_not_argued():
         assert abs(rec[k]["ref_fp16_vs_ref_fp32"] - r16) < 1e-6 * r16 + 1e-9      # same golden file as the record
 
 
+def test_tiny_pixart_kv_compression_and_qk_norm():
+    """Round 6 (review "missing" item 3): PixArt's key / value compression (four samplings, factor 2 in both blocks) and q / k
+    LayerNorm against the imported reference (make_golden.py::tiny_pixart_kvcompress): the FP forward of every sampling, the
+    W8A8 forwards (B = 2 shared token grids, B = 1) of the three the reference can quantize."""
+    from oracle import pixart_ref as pr
+    g = load_npz("tiny_pixart_kvcompress.npz")
+    sd = state_dict_of(g)
+    x, y, mask, t = g["x"], g["y"], g["mask"], g["t"]
+    spec = sr.QSpec(w_bits=8, fp_layers=pr.T2I_FP_LAYERS)
+    for samp in ("conv", "ave", "uniform", "uniform_every"):
+        cfg = dict(H=4, depth=2, patch=2, out_ch=8, qk_norm=True, kv=dict(sampling=samp, sr=2, layers=[0, 1]))
+        fp = pr.pixart_forward(sd, cfg, x, t, y, mask, sr.QSpec(quant=False), g["pos_embed"])
+        assert rel_l2(fp, g["fp_" + samp]) < 1e-5, (samp, rel_l2(fp, g["fp_" + samp]))
+        if samp == "conv":
+            continue
+        out = pr.pixart_forward(sd, cfg, x, t, y, mask, spec, g["pos_embed"])
+        assert rel_l2(out, g["w8a8_" + samp]) < 1e-5, (samp, rel_l2(out, g["w8a8_" + samp]))
+        out1 = pr.pixart_forward(sd, cfg, x[:1], t[:1], y[:1], mask[:1], spec, g["pos_embed"])
+        assert rel_l2(out1, g["w8a8_b1_" + samp]) < 1e-5, samp
+    assert torch.equal(g["fp_ave"], g["fp_uniform"])       # nearest interpolation by 1/2 picks what [::2, ::2] picks
+    assert not torch.equal(g["fp_uniform"], g["fp_uniform_every"])
+
+
 def test_dpm_solver_modes_against_the_reference():
     """Round 6 (review "missing" item 4): every mode of the reference's DPM_Solver.sample the t2i script does not select -
     multistep order 3, the singlestep schedules (orders 1-3, every remainder of steps mod order), singlestep_fixed, the

@@ -11,7 +11,7 @@ Unlike t2v, final_layer.linear is NOT in the t2i FP list and is quantized (SURVE
 Block = STDiT block without the temporal branch (PixArtMS.py:71-79); the fused route reuses the same
 kernels: LN+modulate+quant -> fused-qkv int8 GEMM -> flash attention over N tokens (4096 at 1024^2)
 -> proj GEMM (+gate, +residual) -> varlen cross attention -> MLP.  kv-compression (sr_ratio > 1) and
-qk_norm are not used by the quantized configs and raise NotImplementedError.
+qk_norm are not used by the quantized configs; they are implemented (round 6) with their FP parts as torch ops around the HIP attention.
 """
 from __future__ import annotations
 
@@ -20,6 +20,7 @@ from typing import List
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from ..qdiff.models.quant_block import QuantAttention
@@ -81,32 +82,98 @@ class SizeEmbedder(TimestepEmbedder):
 
 
 class AttentionKVCompress(nn.Module):
-    """Self-attention with a fused qkv Linear (PixArt_blocks.py:63-160, sr_ratio == 1)."""
+    """Self-attention with a fused qkv Linear, optional LayerNorm on q / k and optional compression of the key / value tokens
+    (PixArt_blocks.py:63-160).  ``sampling`` in (None, 'conv', 'ave', 'uniform', 'uniform_every'), ``sr_ratio`` the factor per
+    image axis, ``qk_norm``: LayerNorm over all ``dim`` channels (affine) before the heads are split.  No released quantized
+    config turns these on; they are here so that a PixArt checkpoint trained with them loads and runs (round 6).
+    The attention itself is the HIP kernel with Lq = N queries and Lk = N / sr^2 keys; the LayerNorms, the token picks and
+    the depthwise convolution of 'conv' are torch ops on the fp16 q | k | v buffer (they are FP in the reference as well)."""
+
+    SAMPLINGS = (None, "conv", "ave", "uniform", "uniform_every")
 
     def __init__(self, dim, num_heads=8, qkv_bias=True, sampling=None, sr_ratio=1, qk_norm=False):
         super().__init__()
-        if sr_ratio != 1 or qk_norm:
-            raise NotImplementedError("kv compression / qk_norm are not used by the quantized PixArt configs")
+        if sampling not in self.SAMPLINGS:
+            raise ValueError("sampling is one of %r, got %r" % (self.SAMPLINGS, sampling))
         self.num_heads, self.head_dim = num_heads, dim // num_heads
         self.scale = self.head_dim ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
+        self.sampling, self.sr_ratio = sampling, int(sr_ratio)
+        if self.sr_ratio > 1 and sampling == "conv":                   # average-pool initialisation (PixArt_blocks.py:86-91)
+            self.sr = nn.Conv2d(dim, dim, groups=dim, kernel_size=self.sr_ratio, stride=self.sr_ratio)
+            self.sr.weight.data.fill_(1 / self.sr_ratio ** 2)
+            self.sr.bias.data.zero_()
+            self.norm = nn.LayerNorm(dim)
+        self.q_norm = nn.LayerNorm(dim) if qk_norm else nn.Identity()
+        self.k_norm = nn.LayerNorm(dim) if qk_norm else nn.Identity()
         self.core = QuantAttention(num_heads, self.head_dim)
+
+    @property
+    def plain(self) -> bool:
+        """No q / k LayerNorm, no compression: attention straight on the q | k | v buffer."""
+        return self.sr_ratio <= 1 and isinstance(self.q_norm, nn.Identity)
+
+    def _norm_fp32(self, ln, tns):
+        if isinstance(ln, nn.Identity):
+            return tns
+        return F.layer_norm(tns.float(), ln.normalized_shape, ln.weight.float(), ln.bias.float(), ln.eps).to(tns.dtype)
+
+    def downsample_2d(self, tns, H, W):
+        """[B, N, C] tokens of an H x W grid -> [B, N / sr^2, C] (PixArt_blocks.py:99-124)."""
+        sr, B, C = self.sr_ratio, tns.shape[0], tns.shape[-1]
+        if self.sampling is None or sr <= 1:
+            return tns
+        if self.sampling == "uniform_every":
+            return tns[:, ::sr].contiguous()
+        g = tns.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        if self.sampling == "ave":                                     # nearest-neighbour picks (no averaging, despite the name)
+            g = F.interpolate(g, scale_factor=1 / sr, mode="nearest").permute(0, 2, 3, 1)
+        elif self.sampling == "uniform":
+            g = g[:, :, ::sr, ::sr].permute(0, 2, 3, 1)
+        else:                                                          # 'conv'
+            if isinstance(self.sr, QuantLayer) and any(self.sr.get_quant_state()):
+                # the reference wraps `attn.sr` as a QuantAttnLinearImg and dies in its forward on the 4-D input: there is no
+                # behaviour to match
+                raise NotImplementedError("a quantized `attn.sr` convolution: the reference cannot run it either - keep "
+                                          "'attn.sr' in fp_layer_list")
+            # (an FP-listed `attn.sr` is a QuantLayer in the FP state aliasing the convolution's parameters)
+            g = F.conv2d(g.float(), self.sr.weight.float(), self.sr.bias.float(), stride=sr, groups=C)
+            g = g.reshape(B, C, -1).permute(0, 2, 1)
+            g = self._norm_fp32(self.norm, g).to(tns.dtype)
+        return g.reshape(B, int(H / sr) * int(W / sr), C).contiguous()
+
+    def attend(self, qkv, B, N, HW=None):
+        """qkv [B*N, 3C] fp16 (q | k | v column blocks) -> [B*N, C] fp16."""
+        if self.plain:
+            return self.core.spatial(qkv, B, N)
+        C = self.num_heads * self.head_dim
+        H, W = HW if HW is not None else (int(N ** 0.5), int(N ** 0.5))
+        q3 = self._norm_fp32(self.q_norm, qkv[:, :C].reshape(B, N, C)).contiguous()
+        k3 = self._norm_fp32(self.k_norm, qkv[:, C:2 * C].reshape(B, N, C))
+        k3 = self.downsample_2d(k3, H, W).contiguous()
+        v3 = self.downsample_2d(qkv[:, 2 * C:].reshape(B, N, C), H, W).contiguous()
+        Lk = k3.shape[1]
+        out = torch.empty((B * N, C), dtype=torch.float16, device=qkv.device)
+        ops.attn_fwd(q3.reshape(B * N, C), k3.reshape(B * Lk, C), v3.reshape(B * Lk, C), out, B, N, Lk, self.num_heads,
+                     self.head_dim, N * C, C, Lk * C, C, N * C, C, scale=self.scale)
+        return out
 
     def forward(self, x, mask=None, HW=None, block_id=None):
         B, N, C = x.shape
         dt = x.dtype
         qkv = self.qkv(x).reshape(B * N, 3 * C).half().contiguous()   # q | k | v column blocks (qkv.reshape(B,N,3,C))
-        o = self.core.spatial(qkv, B, N)
+        o = self.attend(qkv, B, N, HW)
         return self.proj(o.reshape(B, N, C).to(dt))
 
 
 class PixArtMSBlock(nn.Module):
-    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, **unused):
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, sampling=None, sr_ratio=1, qk_norm=False, **unused):
         super().__init__()
         self.hidden_size = hidden_size
         self.norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
-        self.attn = AttentionKVCompress(hidden_size, num_heads=num_heads, qkv_bias=True)
+        self.attn = AttentionKVCompress(hidden_size, num_heads=num_heads, qkv_bias=True, sampling=sampling, sr_ratio=sr_ratio,
+                                        qk_norm=qk_norm)
         self.cross_attn = MultiHeadCrossAttention(hidden_size, num_heads)
         self.norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
         self.mlp = Mlp(in_features=hidden_size, hidden_features=int(hidden_size * mlp_ratio), act_layer=approx_gelu)
@@ -139,7 +206,7 @@ class PixArtMSBlock(nn.Module):
         x = x + gate_mlp * self.mlp(t2i_modulate(self.norm2(x), shift_mlp, scale_mlp))
         return x
 
-    def forward_fused(self, x2, y2, t0, kv_off, B):
+    def forward_fused(self, x2, y2, t0, kv_off, B, HW=None):
         """In-place update of x2 [B*N, C] fp16 (hot path; same kernel sequence as the STDiT block minus
         the temporal branch)."""
         C = self.hidden_size
@@ -158,7 +225,7 @@ class PixArtMSBlock(nn.Module):
         r, s = sv(a1.qkv)
         qa = STDiTBlock._ln_quant(x3, shift_msa, scale_msa, (a1.qkv,), [s], st)[0]   # dynamic or calibrated static grid
         qkv = ops.gemm_i8(qa, a1.qkv.packed_weight(r, s), bias=a1.qkv.bias_f32())
-        att_o = a1.core.spatial(qkv, B, N)
+        att_o = a1.attend(qkv, B, N, HW)                   # (plain: the HIP kernel straight on the q | k | v buffer)
         r, s = sv(a1.proj)
         qa = a1.proj.quantize_input(att_o.view(B, N, C), s)
         ops.gemm_i8(qa, a1.proj.packed_weight(r, s), bias=a1.proj.bias_f32(), out=x2, epilogue=ops.EPI_GATE_RESID,
@@ -222,13 +289,18 @@ class _PixArtBase(nn.Module):
         self.y_embedder = CaptionEmbedder(in_channels=caption_channels, hidden_size=hidden_size,
                                           uncond_prob=class_dropout_prob, act_layer=approx_gelu,
                                           token_num=model_max_length)
-        if qk_norm or (kv_compress_config is not None and kv_compress_config.get("kv_compress_layer")):
-            raise NotImplementedError("kv compression / qk_norm are not used by the quantized PixArt configs")
+        # PixArt.py:113-128 / PixArtMS.py:145-157: which blocks compress their keys / values, how, and the q / k LayerNorm
+        self.qk_norm = bool(qk_norm)
+        self.kv_compress_config = kv_compress_config or {"sampling": None, "scale_factor": 1, "kv_compress_layer": []}
         self.h = self.w = 0
         self._mask_cache = None
 
     def _make_blocks(self, hidden_size, num_heads, mlp_ratio, depth, patch_size):
-        self.blocks = nn.ModuleList([self.block_cls(hidden_size, num_heads, mlp_ratio=mlp_ratio) for _ in range(depth)])
+        kc = self.kv_compress_config
+        self.blocks = nn.ModuleList([
+            self.block_cls(hidden_size, num_heads, mlp_ratio=mlp_ratio, sampling=kc["sampling"],
+                           sr_ratio=int(kc["scale_factor"]) if i in kc["kv_compress_layer"] else 1, qk_norm=self.qk_norm)
+            for i in range(depth)])
         self.final_layer = T2IFinalLayer(hidden_size, patch_size * patch_size, self.out_channels)
 
     def initialize_weights(self):
@@ -284,7 +356,7 @@ class _PixArtBase(nn.Module):
                     off = seq_offsets(y_lens, x.device)
                     t0c = t0.contiguous()
                 x2 = x.reshape(bs * N, C)
-                block.forward_fused(x2, y2, t0c, off, bs)
+                block.forward_fused(x2, y2, t0c, off, bs, HW=(self.h, self.w))
                 x = x2.reshape(bs, N, C)
             else:
                 x = block(x, y, t0, y_lens, HW=(self.h, self.w))
