@@ -83,7 +83,9 @@ if "cross" in WHICH:
 
     def f():
         i[0] = (i[0] + 1) % len(qs)
-        ops.attn_fwd(qs[i[0]], kv, kv[:, 1152:], o, 1, 16384, 0, H, D, 16384 * 1152, 1152, 0, 2304, 16384 * 1152, 1152, kv_off=off)
+        # Lk = the bound on every sample's kv length, as QuantAttention.cross passes it (with Lk = 0 the dispatcher cannot
+        # know the keys fit two tiles and takes the generic kernel: what this tool timed until round 6, call 20)
+        ops.attn_fwd(qs[i[0]], kv, kv[:, 1152:], o, 1, 16384, 120, H, D, 16384 * 1152, 1152, 0, 2304, 16384 * 1152, 1152, kv_off=off)
     out.append("cross 16384x120 %.1f us" % timeit(f))
 if "temporal" in WHICH:
     qkvs = [torch.randn(16384, 3456, generator=g).half().to(dev) for _ in range(3)]

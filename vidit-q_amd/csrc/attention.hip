@@ -2093,8 +2093,15 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
             half8 pf[2];
             {
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {                    // plain v_fma_f32 as in attn_fwd32d_kernel (here memory-bound: 42.2 vs 42.4 us, round 6)
+                for (int r = 0; r < 16; r += 2) {                    // plain v_fma_f32 as in attn_fwd32d_kernel: 30.0-31.2 vs 31.2-32.4 us (profiles/r06_experiments.md 8)
+#if defined(VQ_CROSS_PKFMA) && VQ_CROSS_PKFMA
+                    const float2v cc2 = {a.c, a.c}, mm2 = {-mc, -mc};
+                    float2v t = {s[r], s[r + 1]};
+                    t = __builtin_elementwise_fma(t, cc2, mm2);      // v_pk_fma_f32 (rounds 4-5; lab builds)
+                    const float t0 = t[0], t1 = t[1];
+#else
                     const float t0 = __builtin_fmaf(s[r], a.c, -mc), t1 = __builtin_fmaf(s[r + 1], a.c, -mc);
+#endif
                     pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(t0);
                     pf[r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(t1);
                 }
@@ -2139,7 +2146,8 @@ static int launch_cross32(const AttnArgs& a, hipStream_t st) {
     // two 8-wave workgroups per CU (four waves per SIMD); the (sequence, head) pairs share the chip, every workgroup
     // walks >= 1 query tile of 256
     const int G = a.n_seq * a.H, nqt = (a.Lq + 32 * NW - 1) / (32 * NW);
-    int nslice = (2 * ncu + G - 1) / G;
+    static const int wg_per_cu = getenv("VQ_CROSS_WGS") ? atoi(getenv("VQ_CROSS_WGS")) : 2;   // (measurement switch, round 6: 1 / 3 / 4)
+    int nslice = (wg_per_cu * ncu + G - 1) / G;
     nslice = nslice < 1 ? 1 : (nslice > nqt ? nqt : nslice);
     const int s8 = (nslice + 7) / 8;                      // slices are dealt to the 8 XCDs: grid padded to a multiple
     hipLaunchKernelGGL(k, dim3(8 * s8 * G), dim3(64 * NW), LDS, st, a, nslice);
