@@ -818,6 +818,8 @@ def main():
             for plan, r in zip(("w4a8", "w4a8_mp"), legs):
                 extras[plan] = {"value": r["steps"] / r["el"], "unit": "denoising steps/s", "steps": r["steps"], "warmup": EXTRA_WARMUP,
                                 "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"], "telemetry": r.get("telemetry"),
+                                "host_graph_launch_ms_idle_queue": r.get("host_graph_launch_ms_idle_queue"),
+                                "graph_nodes": (r.get("graph_nodes") or {}).get("c_abi_calls_per_step"),
                                 "ms_per_step": r["el"] / r["steps"] * 1e3, "schedule": "DDIM-%d" % r["n_sampling"],
                                 "status_word": r["status"],
                                 "gemm_frac_of_int8_peak": r["roofline"]["frac"] if r["roofline"] else None,
