@@ -206,7 +206,7 @@ def main():
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["stdit_full", "stdit_full_w4a8", "sigma1024_full"]
     hip, src = _hip_figures()
     res = {}
-    prev = OUT if os.path.exists(OUT) else os.path.join(ROOT, "profiles", "r05_parity_floor.json")
+    prev = OUT if os.path.exists(OUT) else os.path.join(ROOT, "profiles", "r06_parity_floor.json")   # (records carry over between rounds)
     if os.path.exists(prev):
         with open(prev) as f:
             res = json.load(f).get("records", {})
