@@ -735,10 +735,14 @@ def test_attn_fwd_cross_varlen(ops, dev):
 
 
 @pytest.mark.parametrize("B,Nq,H,lens", [(2, 4096, 16, [300, 257]), (3, 777, 16, [129, 300, 17]), (1, 4096, 16, [300]),
-                                         (2, 100, 4, [300, 1])])
+                                         (2, 100, 4, [300, 1]), (2, 4096, 16, [180, 150]), (1, 1024, 16, [250]),
+                                         (2, 300, 8, [320, 193]), (1, 512, 16, [321])])
 def test_attn_cross_varlen_long_prompts(ops, dev, B, Nq, H, lens):
-    """PixArt-Sigma prompts: up to 300 T5 tokens (quant_txt2img.py:207-208) - more than the 128 keys the
-    register-resident kernel holds, so the general varlen kernel runs (bound = longest prompt, and unknown bound)."""
+    """PixArt-Sigma prompts: up to 300 T5 tokens (quant_txt2img.py:207-208) - more than the 128 keys of two tile images.
+    Round 6: with the bound the model passes (the longest prompt, <= 320) and >= 256 queries the LDS-resident kernel runs
+    with 3 / 4 / 5 tile images (bounds 129-192 / 193-256 / 257-320: every instantiation here, ragged last halves, a sample
+    with one or 17 keys beside a long one); an unknown bound (0), a bound above 320 or few queries take the general varlen
+    kernel."""
     D = 72
     Cc = H * D
     q = h16(B * Nq, Cc, seed=Nq + 5).to(dev)

@@ -1893,8 +1893,11 @@ static int launch_attn64d(const AttnArgs& a, hipStream_t st) {
 // reads - as much as the kernel's HBM traffic).  Here a wave needs ~128 VGPRs: four waves per SIMD, 32 queries each,
 // and the K / V images are staged by LDS-DMA once per 8 waves.
 // ---------------------------------------------------------------------------
-template <int D, int NW = 8>
-__global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs a, int nslice) {
+// NT (round 6): 64-key tile images resident in LDS - 2 for the <= 128 prompt tokens of STDiT / PixArt-alpha (two workgroups per
+// CU), 3 ... 5 for PixArt-Sigma's prompts of up to 300 tokens (one workgroup per CU; the generic kernel those launches took
+// restaged K / V per 128 queries: 25.4 us per launch, 5 % of that step).
+template <int D, int NW = 8, int NT = 2>
+__global__ __launch_bounds__(64 * NW, NT == 2 ? 32 / NW : 16 / NW) void attn_cross32_kernel(AttnArgs a, int nslice) {
     using C = Att8Cfg<D, NW>;
     constexpr int KT = 64, KTB = C::KTILE, VRB = 192, VT = KT * VRB;
     constexpr int KSL = C::KROW / 16, VSL = VRB / 16;       // 16-byte slots per row
@@ -1923,13 +1926,13 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
         kbase = a.k + (long)seq * a.kv_seq_stride + h * D;
         vbase = a.v + (long)seq * a.kv_seq_stride + h * D;
     }
-    kv_len = kv_len < 2 * KT ? kv_len : 2 * KT;            // host guarantees <= 128
+    kv_len = kv_len < NT * KT ? kv_len : NT * KT;          // host guarantees <= NT * 64
     const int nkt = (kv_len + KT - 1) / KT;
     const int strideB = (int)a.kv_tok_stride * 2;
     const unsigned nrec = kv_len > 0 ? (unsigned)(kv_len - 1) * (unsigned)strideB + D * 2 : 0u;
     // ---- prologue: both tile images by LDS-DMA (rows past the last key are outside num_records: zeros)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < NT; ++kt) {
         const unsigned t0 = (unsigned)kt * (unsigned)KT * (unsigned)strideB;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
@@ -1947,16 +1950,16 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
                                   (int)__builtin_amdgcn_readfirstlane(nrec > t0 ? nrec - t0 : 0u), 0x00020000};
                 const unsigned dst = __builtin_amdgcn_readfirstlane(
                     (unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)smem +
-                    (isk ? kt * KTB + j * 1024 : 2 * KTB + kt * VT + (j - NKI) * 1024));
+                    (isk ? kt * KTB + j * 1024 : NT * KTB + kt * VT + (j - NKI) * 1024));
                 if (piece < C::CHD)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff), "s"(rs)
                                  : "memory", "m0");
             }
         }
     }
-    for (int i = tid; i < 2 * KT * 3; i += 64 * NW) {   // pad columns of both V images: column D = 1.0, the rest 0
+    for (int i = tid; i < NT * KT * 3; i += 64 * NW) {   // pad columns of every V image: column D = 1.0, the rest 0
         const int r = i / 3, ch = i % 3;
-        *reinterpret_cast<int4v*>(smem + 2 * KTB + r * VRB + D * 2 + ch * 16) = int4v{ch == 0 ? 0x00003c00 : 0, 0, 0, 0};
+        *reinterpret_cast<int4v*>(smem + NT * KTB + r * VRB + D * 2 + ch * 16) = int4v{ch == 0 ? 0x00003c00 : 0, 0, 0, 0};
     }
     const int nqt = (a.Lq + 32 * NW - 1) / (32 * NW);
     const half_t* qseq = a.q + (long)seq * a.q_seq_stride + h * D;
@@ -1966,7 +1969,7 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
     // fragment loads this replaces touched 32 rows x 32 bytes per instruction), requested one tile ahead; the MFMA
     // operand fragments are then ds_read_b128 of that image (conflict-free: odd number of slots per row).
     constexpr int QSL = C::KROW / 16, QW = 32 * C::KROW, NQI = (32 * QSL + 63) / 64;
-    uint8_t* qreg = smem + 2 * KTB + 2 * VT + wave * QW;
+    uint8_t* qreg = smem + NT * KTB + NT * VT + wave * QW;
     const unsigned qdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint8_t*)qreg);
     int qvoff[NQI];
     bool qok[NQI];
@@ -2006,9 +2009,9 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
     const int vtr0 = (4 * g + ((lane & 15) >> 2)) * VRB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     constexpr int LD_T = D / 32, LD_R = D % 32;
     constexpr int LD_G = (LD_R >> 2) & 1, LD_REG = (LD_R & 3) + 4 * (LD_R >> 3);
-    const int nhalf = (kv_len + 31) / 32;                  // 32-key half tiles that hold keys (wave-uniform, 1..4)
+    const int nhalf = (kv_len + 31) / 32;                  // 32-key half tiles that hold keys (wave-uniform, 1 .. 2 NT)
     const uint8_t* k_l = smem + l31 * C::KROW;
-    const uint8_t* v_l = smem + 2 * KTB + vtr0;
+    const uint8_t* v_l = smem + NT * KTB + vtr0;
 
     for (; qt < nqt; qt += nslice) {
         const int qnext = qt + nslice;
@@ -2127,11 +2130,12 @@ __global__ __launch_bounds__(64 * NW, 32 / NW) void attn_cross32_kernel(AttnArgs
     }
 }
 
-template <int D>
+template <int D, int NT = 2>
 static int launch_cross32(const AttnArgs& a, hipStream_t st) {
     constexpr int NW = 8;
-    constexpr int LDS = 2 * Att8Cfg<D, 8>::KTILE + 2 * 64 * 192 + NW * 32 * Att8Cfg<D, 8>::KROW;
-    auto k = attn_cross32_kernel<D, NW>;
+    constexpr int LDS = NT * Att8Cfg<D, 8>::KTILE + NT * 64 * 192 + NW * 32 * Att8Cfg<D, 8>::KROW;
+    static_assert(LDS <= 163840, "LDS budget of one CU");
+    auto k = attn_cross32_kernel<D, NW, NT>;
     static hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
         g_vq_last_hip_error = (int)e;
@@ -2143,11 +2147,10 @@ static int launch_cross32(const AttnArgs& a, hipStream_t st) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
         return v;
     }();
-    // two 8-wave workgroups per CU (four waves per SIMD); the (sequence, head) pairs share the chip, every workgroup
-    // walks >= 1 query tile of 256
+    // NT == 2: two 8-wave workgroups per CU (four waves per SIMD; 1 / 3 / 4 measured slower, round 6); more tile images: one (LDS).
+    // The (sequence, head) pairs share the chip, every workgroup walks >= 1 query tile of 256
     const int G = a.n_seq * a.H, nqt = (a.Lq + 32 * NW - 1) / (32 * NW);
-    static const int wg_per_cu = getenv("VQ_CROSS_WGS") ? atoi(getenv("VQ_CROSS_WGS")) : 2;   // (measurement switch, round 6: 1 / 3 / 4)
-    int nslice = (wg_per_cu * ncu + G - 1) / G;
+    int nslice = ((NT == 2 ? 2 : 1) * ncu + G - 1) / G;
     nslice = nslice < 1 ? 1 : (nslice > nqt ? nqt : nslice);
     const int s8 = (nslice + 7) / 8;                      // slices are dealt to the 8 XCDs: grid padded to a multiple
     hipLaunchKernelGGL(k, dim3(8 * s8 * G), dim3(64 * NW), LDS, st, a, nslice);
@@ -2395,6 +2398,14 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     if (!old_kernel && !no_reg && !cross_reg && a.Lk > 0 && a.Lk <= 128 && a.Lq >= 256 &&
         (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31))
         return launch_cross32<D>(a, st);
+    // round 6: prompts of up to 320 tokens (PixArt-Sigma: 300) with every sample's keys given by offsets - K / V of a
+    // (sequence, head) pair resident in 3 ... 5 tile images, one workgroup per CU.  VQ_ATTN_CROSS_LONG=0: the generic kernel (A/B)
+    static const bool no_long = getenv("VQ_ATTN_CROSS_LONG") && atoi(getenv("VQ_ATTN_CROSS_LONG")) == 0;
+    if constexpr (D >= 64) {
+        if (!old_kernel && !no_reg && !cross_reg && !no_long && a.kv_off && a.Lk > 128 && a.Lk <= 320 && a.Lq >= 256 &&
+            (long)a.Lk * a.kv_tok_stride * 2 < (1l << 31))
+            return a.Lk <= 192 ? launch_cross32<D, 3>(a, st) : a.Lk <= 256 ? launch_cross32<D, 4>(a, st) : launch_cross32<D, 5>(a, st);
+    }
     if (D == 72 && !old_kernel && !no_reg && a.Lk > 0 && a.Lk <= 128 && a.H % 8 == 0 && a.Lq >= 64) return launch_cross_reg(a, st);
     if (!old_kernel && !a.kv_off && a.Lk > 128 && a.Lq >= 96)
     {
